@@ -1,0 +1,169 @@
+/*
+ * kanvit.h -- C ABI of the MI355X (gfx950) hot-path library for the ViKANformer
+ * reference (akshathmangudi/KAN-ViT).
+ *
+ * The reference has no native / FFI layer at all: its boundary is the Python
+ * nn.Module surface.  This header is the boundary the
+ * replacement adds UNDERNEATH that surface; each entry point below cites the
+ * reference function whose arithmetic it replaces (paths relative to the
+ * reference repository root).
+ *
+ * Conventions (all entry points)
+ *   - plain C types only; every pointer is a BORROWED device pointer to fp32
+ *     data owned by the caller (a torch tensor, a hipMalloc block, ...), which
+ *     must stay alive until the work queued on `stream` has completed;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); no internal synchronisation, no allocation, graph-capturable;
+ *   - returns 0 on success, a negative KANVIT_E* code otherwise; never throws,
+ *     never exits; kanvit_last_error() gives a thread-local message;
+ *   - re-entrant and thread safe for distinct streams.
+ */
+#ifndef KANVIT_H
+#define KANVIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KANVIT_ABI_VERSION 1
+
+/* error codes */
+#define KANVIT_OK 0
+#define KANVIT_EINVAL (-22)      /* bad descriptor / unsupported shape          */
+#define KANVIT_ENOMEM (-12)      /* workspace too small                         */
+#define KANVIT_EDEVICE (-5)      /* HIP runtime error (no device, launch error) */
+
+/* basis families: phi_g(x) generated on the fly, never stored in HBM */
+#define KANVIT_LINEAR 0   /* phi = x                               nn.Linear in attention.py:136-142           */
+#define KANVIT_CHEBY 1    /* T_g(tanh x), g = 0..degree            models/cheby.py:36-48                       */
+#define KANVIT_BSPLINE 2  /* Cox-de Boor B-splines (+ silu base)   models/effkan.py:99-132,174-187             */
+#define KANVIT_RBF 3      /* exp(-((u-c_g)/h)^2) (+ silu base)     models/fastkan.py:29-30,66-76               */
+#define KANVIT_SINE 4     /* sin(x f_g + p_ig)                     models/sinekan.py:81-91                     */
+#define KANVIT_FOURIER 5  /* cos(k x), sin(k x), k = 1..G          models/nfkan.py:36-52                       */
+
+/*
+ * One launch evaluates `groups` independent KAN layers that share M rows:
+ *   y[m, g*O + o] = bias[g][o] + sum_i sum_j phi_j(x[m, (g % x_group_mod)*I + i]) * w[g][i*GP + j][o]
+ * groups = 1 is a plain layer (patch embedding, model.py:146); groups = 3*H with
+ * x_group_mod = H is the per-head q|k|v mapping of MSA (attention.py:191-197)
+ * folded over the batch, group index = proj*H + head.
+ *
+ * GP (generated columns per input feature):
+ *   LINEAR 1 | CHEBY G | BSPLINE G+has_base | RBF G+has_base | SINE G | FOURIER 2G
+ * Packed weights w: [groups][I*GP][O] row-major, k = i*GP + j, with j ordered
+ *   CHEBY   j = degree d                      (cheby_coeffs[i][o][d])
+ *   BSPLINE j = basis 0..G-1, then base       (spline_weight*spline_scaler [o][i][j], base_weight[o][i])
+ *   RBF     j = centre 0..G-1, then base      (spline_linear.weight[o][i*G+j], base_linear.weight[o][i])
+ *   SINE    j = g                             (amplitudes[o][i][g])
+ *   FOURIER j = c*G + (k-1), c = 0 cos, 1 sin (fouriercoeffs[c][o][i][k-1])
+ * Basis parameters bparams: [groups][bparam_stride] floats per group
+ *   BSPLINE knots[I][G+spline_order+1] | RBF centres[G] | SINE freq[G] then phase[I][G] | others: none (NULL)
+ */
+typedef struct kanvit_layer_desc {
+    int32_t family;        /* KANVIT_*                                                      */
+    int32_t groups;        /* independent layers in this launch (>= 1)                      */
+    int32_t x_group_mod;   /* group g reads x columns [(g % x_group_mod)*I, +I)             */
+    int32_t I;             /* input features per group                                      */
+    int32_t O;             /* output features per group                                     */
+    int32_t G;             /* cheby: degree+1; bspline: grid_size+spline_order; rbf: num_grids;
+                              sine: grid_size; fourier: gridsize; linear: 1                 */
+    int32_t spline_order;  /* BSPLINE only                                                  */
+    int32_t has_base;      /* BSPLINE / RBF: extra silu(x) column per input feature         */
+    float rbf_inv_h;       /* RBF: 1 / denominator                                          */
+    int32_t reserved;
+    int64_t M;             /* rows                                                          */
+    int64_t ldx;           /* row stride (floats) of x and dx                               */
+    int64_t ldu;           /* row stride of u and du (RBF; group g uses columns [g*I, +I))  */
+    int64_t ldy;           /* row stride of y and dy (group g uses columns [g*O, +O))       */
+    int64_t bparam_stride; /* floats between consecutive groups in bparams                  */
+} kanvit_layer_desc;
+
+/* ---- fused basis evaluation + coefficient contraction -------------------------------------
+ * forward of models/cheby.py:36-48, models/effkan.py:174-187, models/fastkan.py:66-76 (the
+ * LayerNorm of :68 is applied by the caller and passed as u; u = NULL means u = x),
+ * models/nfkan.py:36-52, models/sinekan.py:81-91, and nn.Linear (attention.py:136-142).      */
+int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u, const float* w,
+                     const float* bparams, const float* bias, float* y, void* stream);
+
+/* ---- backward w.r.t. the layer input (what torch.autograd derives for the reference) ------
+ * dx[m, c*I + i] = sum over the groups g with g % x_group_mod == c of
+ *                  sum_j phi_j'(x) * sum_o dy[m, g*O+o] * w[g][i*GP+j][o]     (written, not accumulated)
+ * RBF: du[m, g*I+i] gets the spline-path gradient, dx the base-path gradient.
+ * SINE: dparam receives per-row-tile partial sums of d loss / d freq, shape
+ *       [kanvit_layer_dparam_tiles(d)][groups][G]; the caller sums over dim 0.                */
+int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const float* u, const float* w,
+                           const float* bparams, const float* dy, float* dx, float* du, float* dparam,
+                           void* stream);
+int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d);
+
+/* ---- backward w.r.t. the packed weights ---------------------------------------------------
+ * dw[g][i*GP+j][o] = sum_m phi_j(x[m, ...i]) * dy[m, g*O+o]; split over row ranges into
+ * partial slabs in `workspace`, then reduced in a fixed order (deterministic, no atomics).   */
+size_t kanvit_layer_bwd_weight_workspace(const kanvit_layer_desc* d);
+int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const float* u, const float* bparams,
+                            const float* dy, float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- multi-head attention core ------------------------------------------------------------
+ * o = softmax(q k^T * scale) v per (batch, head); replaces attention.py:199-200 (MSA) and
+ * utils.py:137-227 (FlashAttentionFunction.forward; lse is what it saves for backward).
+ * Element (b, h, n, c) of q/k/v/o lives at base[b*stride_b + h*stride_h + n*stride_n + c];
+ * lse is [B][H][N] contiguous.  D even, D <= KANVIT_ATTN_MAX_D; one head must fit the 160 KiB
+ * LDS of a CU: N <= 256 for D <= 32, N <= 224 for D <= 64.                                   */
+#define KANVIT_ATTN_MAX_N 256
+#define KANVIT_ATTN_MAX_D 64
+typedef struct kanvit_attn_desc {
+    int32_t B, H, N, D;
+    int32_t causal;         /* utils.py:177-180 with equal q/k lengths */
+    float scale;            /* D^-1/2 in both callers */
+    int64_t q_stride_b, q_stride_h, q_stride_n;
+    int64_t k_stride_b, k_stride_h, k_stride_n;
+    int64_t v_stride_b, v_stride_h, v_stride_n;
+    int64_t o_stride_b, o_stride_h, o_stride_n;   /* also the layout of do; dq/dk/dv use the q/k/v strides */
+} kanvit_attn_desc;
+
+int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, const float* v,
+                    float* o, float* lse, void* stream);
+/* backward of the above; replaces utils.py:229-295 (recompute p from q, k, lse).
+ * workspace: kanvit_attn_bwd_workspace(d) bytes (holds rowsum(dO*O), "D" of utils.py:286). */
+size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d);
+int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, const float* v,
+                    const float* o, const float* lse, const float* d_o,
+                    float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-family named entry points (SURVEY.md section 8b naming) ----------------------------
+ * kanvit_<family>_{fwd,bwd_input,bwd_weight} are kanvit_layer_* with d->family checked;
+ * kanvit_<family>_qkv_* additionally require groups == 3 * x_group_mod (one launch for all
+ * heads' q, k and v mappings).                                                                 */
+#define KANVIT_DECLARE_FAMILY(name)                                                                           \
+    int kanvit_##name##_fwd(const kanvit_layer_desc*, const float*, const float*, const float*, const float*, \
+                            const float*, float*, void*);                                                     \
+    int kanvit_##name##_bwd_input(const kanvit_layer_desc*, const float*, const float*, const float*,         \
+                                  const float*, const float*, float*, float*, float*, void*);                 \
+    int kanvit_##name##_bwd_weight(const kanvit_layer_desc*, const float*, const float*, const float*,        \
+                                   const float*, float*, void*, size_t, void*);                               \
+    int kanvit_##name##_qkv_fwd(const kanvit_layer_desc*, const float*, const float*, const float*,           \
+                                const float*, const float*, float*, void*);                                   \
+    int kanvit_##name##_qkv_bwd_input(const kanvit_layer_desc*, const float*, const float*, const float*,     \
+                                      const float*, const float*, float*, float*, float*, void*);             \
+    int kanvit_##name##_qkv_bwd_weight(const kanvit_layer_desc*, const float*, const float*, const float*,    \
+                                       const float*, float*, void*, size_t, void*);
+KANVIT_DECLARE_FAMILY(linear)
+KANVIT_DECLARE_FAMILY(cheby)
+KANVIT_DECLARE_FAMILY(bspline)
+KANVIT_DECLARE_FAMILY(rbf)
+KANVIT_DECLARE_FAMILY(sine)
+KANVIT_DECLARE_FAMILY(fourier)
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+int kanvit_abi_version(void);
+const char* kanvit_last_error(void);
+/* number of HIP devices visible, or a negative error code; does not initialise a context */
+int kanvit_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KANVIT_H */

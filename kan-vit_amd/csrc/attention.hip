@@ -1,0 +1,522 @@
+// Multi-head attention core for gfx950, fp32-exact MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces attention.py:199-200 (softmax(q k^T / sqrt(dh)) v inside MSA's python double loop) and
+// utils.py:137-295 (FlashAttentionFunction forward / recompute backward).  Sequence lengths on
+// this path are 17 / 50 / 197, so a whole head fits one workgroup:
+// no online rescaling, no cross-workgroup reductions, bitwise run-to-run reproducible.
+//
+// One workgroup = one (batch, head), 4 waves; a wave owns 32-query (or 32-key) tiles.
+// Layout trick used throughout (cdna guide section 3, "accumulator tile as the next MFMA's
+// operand", fp32 form): the first product is oriented so the reduction index of the SECOND
+// product lands in the accumulator's register index.  For the 32x32x2 shape the k-step r of the
+// second product then takes B[k = lane>>5][col = lane&31] = accumulator register r directly,
+// with the other operand fetched from LDS row kv_acc_row(r, lane>>5) -- no LDS round trip and
+// no cross-lane traffic for P, dS.
+//
+// LDS tiles are [rows][KS] with KS = 32*DT + 1 (odd): conflict free both when lanes walk rows
+// (A operand of q.k^T) and when lanes walk columns (A operand of the second products).  Columns
+// D..32*DT-1 and rows N..NP-1 are zero.
+#include "kanvit_common.h"
+
+namespace {
+
+constexpr int ATHR = 256;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnArgs {
+    const float* q;
+    const float* k;
+    const float* v;
+    const float* o;
+    const float* lse_in;
+    const float* d_o;
+    const float* delta_in;
+    float* out;
+    float* lse;
+    float* dq;
+    float* dk;
+    float* dv;
+    float* delta;
+    long long qsb, qsh, qsn, ksb, ksh, ksn, vsb, vsh, vsn, osb, osh, osn;
+    int B, H, N, D, causal, nkt;
+    float scale;
+};
+
+template <int DT>
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, long long stride_n,
+                                          int row0, int rows, int N, int D, int tid, int nthr) {
+    constexpr int W = 32 * DT;
+    constexpr int KS = W + 1;
+    for (int idx = tid; idx < rows * W; idx += nthr) {
+        const int r = idx / W, c = idx - r * W;
+        const int n = row0 + r;
+        dst[r * KS + c] = (n < N && c < D) ? src[(long long)n * stride_n + c] : 0.0f;
+    }
+}
+
+// =============================================================================================
+// forward: grid B*H.  NKT = compile-time bound on the number of 32-key tiles (registers).
+// =============================================================================================
+template <int DT, int NKT>
+__global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 32 * DT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, D = a.D, nkt = a.nkt, NP = nkt * 32;
+    float* K_s = smem;                   // [NP][KS]
+    float* V_s = K_s + NP * KS;          // [NP][KS]
+    float* Q_w = V_s + NP * KS + wave * 32 * KS;   // per wave [32][KS]; doubles as the O staging tile
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    float* ob = a.out + bi * a.osb + hi * a.osh;
+
+    load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, ATHR);
+    load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, ATHR);
+
+    const float sc2 = a.scale * LOG2E;
+    const int niter = (nkt + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int qt = it * 4 + wave;        // tiles past nkt run on zero rows and store nothing
+        load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64);
+        __syncthreads();                     // also covers the K/V fill on the first trip
+
+        float qf[16 * DT];
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) qf[s] = Q_w[l31 * KS + 2 * s + hf];
+
+        // S^T tiles: rows = keys, cols = queries
+        f32x16 sacc[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
+            if (j < nkt) {
+                const float* kp = K_s + (j * 32 + l31) * KS + hf;
+#pragma unroll
+                for (int s = 0; s < 16 * DT; ++s)
+                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc[j], 0, 0, 0);
+            }
+        }
+        // softmax over keys: registers of this lane + the partner lane in the other half
+        const int qrow = qt * 32 + l31;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = j * 32 + kv_acc_row(r, hf);
+                    const bool dead = (key >= N) || (a.causal && key > qrow);
+                    const float sv = dead ? -INFINITY : sacc[j][r];
+                    sacc[j][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mxs = (mx == -INFINITY) ? 0.0f : mx * sc2;
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(sacc[j][r] * sc2 - mxs);
+                    sacc[j][r] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // O^T[d][query] = sum_key V[key][d] * P[key][query]
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = sacc[j][r] * inv;
+                    const float* vp = V_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], pv, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                     // everyone is done reading Q_w as Q
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = oacc[dt][r];
+        __syncthreads();
+        if (qt < nkt) {
+            for (int idx = lane; idx < 32 * D; idx += 64) {
+                const int r = idx / D, c = idx - r * D;
+                const int n = qt * 32 + r;
+                if (n < N) ob[(long long)n * a.osn + c] = Q_w[r * KS + c];
+            }
+            if (hf == 0 && qrow < N && a.lse) a.lse[(long long)bh * N + qrow] = mx * a.scale + logf(sum);
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// backward helper: delta[b,h,n] = sum_d dO * O   (utils.py:286, "D")
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
+    const int sub = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long rows = (long long)a.B * a.H * a.N;
+    float s = 0.0f;
+    if (row < rows) {
+        const int n = (int)(row % a.N);
+        const long long bh = row / a.N;
+        const int hi = (int)(bh % a.H);
+        const long long bi = bh / a.H;
+        const float* op = a.o + bi * a.osb + hi * a.osh + (long long)n * a.osn;
+        const float* dp = a.d_o + bi * a.osb + hi * a.osh + (long long)n * a.osn;
+        for (int c = sub; c < a.D; c += 16) s += op[c] * dp[c];
+    }
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    if (row < rows && sub == 0) a.delta[row] = s;
+}
+
+// =============================================================================================
+// backward dK, dV: key-stationary.  A wave owns a 32-key tile (K, V fragments in registers,
+// dK^T / dV^T in accumulators) and sweeps all query tiles; S and dP are computed with the key
+// on the lane so they feed the second products as B operands straight from registers.
+// =============================================================================================
+template <int DT>
+__global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 32 * DT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, D = a.D, nkt = a.nkt, NP = nkt * 32;
+    float* Q_s = smem;                     // [NP][KS]
+    float* dO_s = Q_s + NP * KS;           // [NP][KS]
+    float* lse_s = dO_s + NP * KS;         // [NP]
+    float* dl_s = lse_s + NP;              // [NP]
+    float* T_w = dl_s + NP + wave * 32 * KS;   // per wave staging [32][KS]
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    float* dkb = a.dk + bi * a.ksb + hi * a.ksh;
+    float* dvb = a.dv + bi * a.vsb + hi * a.vsh;
+
+    load_tile<DT>(Q_s, qb, a.qsn, 0, NP, N, D, tid, ATHR);
+    load_tile<DT>(dO_s, dob, a.osn, 0, NP, N, D, tid, ATHR);
+    for (int n = tid; n < NP; n += ATHR) {
+        lse_s[n] = (n < N) ? a.lse_in[(long long)bh * N + n] * LOG2E : INFINITY;   // exp2(-inf) = 0 on pad rows
+        dl_s[n] = (n < N) ? a.delta_in[(long long)bh * N + n] : 0.0f;
+    }
+    const float sc2 = a.scale * LOG2E;
+
+    const int niter = (nkt + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int jt = it * 4 + wave;
+        const int key = jt * 32 + l31;
+        const bool key_ok = (jt < nkt) && (key < N);
+        // K and V fragments of this wave's keys (B operands): stage through the wave's tile
+        float kf[16 * DT], vf[16 * DT];
+        load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
+        __syncthreads();
+        load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
+
+        f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[dt][r] = 0.0f;
+                dvacc[dt][r] = 0.0f;
+            }
+
+        for (int qt = 0; qt < nkt; ++qt) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            const float* qp = Q_s + (qt * 32 + l31) * KS + hf;
+            const float* dp = dO_s + (qt * 32 + l31) * KS + hf;
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * s], kf[s], sacc, 0, 0, 0);    // S[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[2 * s], vf[s], pacc, 0, 0, 0);    // dP[q][key]
+            }
+            // p = exp(s*scale - lse), ds = p * scale * (dp - delta)        (utils.py:278-287)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = qt * 32 + kv_acc_row(r, hf);
+                float p = exp2f(sacc[r] * sc2 - lse_s[qrow]);
+                if (!key_ok || (a.causal && key > qrow)) p = 0.0f;
+                sacc[r] = p;
+                pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (qt * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dO_s[row + dt * 32], sacc[r], dvacc[dt], 0, 0, 0);
+                    dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Q_s[row + dt * 32], pacc[r], dkacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        // write dK, dV tiles through the wave's staging tile (rows = keys, coalesced along d)
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dkacc[dt][r];
+        __syncthreads();
+        if (jt < nkt)
+            for (int idx = lane; idx < 32 * D; idx += 64) {
+                const int r = idx / D, c = idx - r * D;
+                const int n = jt * 32 + r;
+                if (n < N) dkb[(long long)n * a.ksn + c] = T_w[r * KS + c];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dvacc[dt][r];
+        __syncthreads();
+        if (jt < nkt)
+            for (int idx = lane; idx < 32 * D; idx += 64) {
+                const int r = idx / D, c = idx - r * D;
+                const int n = jt * 32 + r;
+                if (n < N) dvb[(long long)n * a.vsn + c] = T_w[r * KS + c];
+            }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// backward dQ: query-stationary mirror of the forward kernel.
+// =============================================================================================
+template <int DT>
+__global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 32 * DT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, D = a.D, nkt = a.nkt, NP = nkt * 32;
+    float* K_s = smem;
+    float* V_s = K_s + NP * KS;
+    float* T_w = V_s + NP * KS + wave * 32 * KS;
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
+
+    load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, ATHR);
+    load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, ATHR);
+    const float sc2 = a.scale * LOG2E;
+
+    const int niter = (nkt + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int qt = it * 4 + wave;
+        const int qrow = qt * 32 + l31;
+        const bool q_ok = (qt < nkt) && (qrow < N);
+        float qf[16 * DT], dof[16 * DT];
+        load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
+        __syncthreads();
+        load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
+        const float lse2 = q_ok ? a.lse_in[(long long)bh * N + qrow] * LOG2E : INFINITY;
+        const float dl = q_ok ? a.delta_in[(long long)bh * N + qrow] : 0.0f;
+
+        f32x16 dqacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+
+        for (int j = 0; j < nkt; ++j) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            const float* kp = K_s + (j * 32 + l31) * KS + hf;
+            const float* vp = V_s + (j * 32 + l31) * KS + hf;
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc, 0, 0, 0);    // S^T[key][q]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], dof[s], pacc, 0, 0, 0);   // dP^T[key][q]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j * 32 + kv_acc_row(r, hf);
+                float p = exp2f(sacc[r] * sc2 - lse2);
+                if (key >= N || (a.causal && key > qrow)) p = 0.0f;
+                pacc[r] = p * a.scale * (pacc[r] - dl);                                          // dS^T
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* kr = K_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[dt * 32], pacc[r], dqacc[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dqacc[dt][r];
+        __syncthreads();
+        if (qt < nkt)
+            for (int idx = lane; idx < 32 * D; idx += 64) {
+                const int r = idx / D, c = idx - r * D;
+                const int n = qt * 32 + r;
+                if (n < N) dqb[(long long)n * a.qsn + c] = T_w[r * KS + c];
+            }
+        __syncthreads();
+    }
+}
+
+int check_desc(const kanvit_attn_desc* d, const char* who) {
+    if (!d) return kv_fail(KANVIT_EINVAL, "%s: null descriptor", who);
+    if (d->B < 0 || d->H < 1 || d->N < 1 || d->D < 1) return kv_fail(KANVIT_EINVAL, "%s: bad sizes", who);
+    if (d->N > KANVIT_ATTN_MAX_N) return kv_fail(KANVIT_EINVAL, "%s: N=%d exceeds %d (one head must fit a workgroup)", who, d->N, KANVIT_ATTN_MAX_N);
+    if (d->D > KANVIT_ATTN_MAX_D || (d->D & 1)) return kv_fail(KANVIT_EINVAL, "%s: D=%d must be even and <= %d", who, d->D, KANVIT_ATTN_MAX_D);
+    if ((long long)d->B * d->H > 0x7fffffffLL) return kv_fail(KANVIT_EINVAL, "%s: B*H too large", who);
+    const int ks = (d->D <= 32 ? 32 : 64) + 1, np = (d->N + 31) / 32 * 32;
+    const size_t lds = sizeof(float) * ((size_t)2 * np * ks + 2 * (size_t)np + (size_t)4 * 32 * ks);
+    if (lds > 160 * 1024)
+        return kv_fail(KANVIT_EINVAL, "%s: N=%d with D=%d needs %zu bytes of LDS (> 160 KiB): one head must fit a CU", who,
+                       d->N, d->D, lds);
+    return 0;
+}
+
+AttnArgs make_args(const kanvit_attn_desc* d) {
+    AttnArgs a{};
+    a.B = d->B; a.H = d->H; a.N = d->N; a.D = d->D; a.causal = d->causal; a.scale = d->scale;
+    a.nkt = (d->N + 31) / 32;
+    a.qsb = d->q_stride_b; a.qsh = d->q_stride_h; a.qsn = d->q_stride_n;
+    a.ksb = d->k_stride_b; a.ksh = d->k_stride_h; a.ksn = d->k_stride_n;
+    a.vsb = d->v_stride_b; a.vsh = d->v_stride_h; a.vsn = d->v_stride_n;
+    a.osb = d->o_stride_b; a.osh = d->o_stride_h; a.osn = d->o_stride_n;
+    return a;
+}
+
+template <int DT, int NKT>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+    constexpr int KS = 32 * DT + 1;
+    const size_t lds = sizeof(float) * ((size_t)2 * a.nkt * 32 * KS + (size_t)4 * 32 * KS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        KV_HIP_CHECK(kv_allow_lds(attn_fwd_kernel<DT, NKT>, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, NKT>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds, st, a);
+    KV_LAUNCH_CHECK("attn_fwd_kernel");
+    return 0;
+}
+
+template <int DT>
+int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
+    if (a.nkt <= 1) return launch_fwd<DT, 1>(a, st);
+    if (a.nkt <= 2) return launch_fwd<DT, 2>(a, st);
+    if (a.nkt <= 4) return launch_fwd<DT, 4>(a, st);
+    if (a.nkt <= 7) return launch_fwd<DT, 7>(a, st);
+    return launch_fwd<DT, 8>(a, st);
+}
+
+template <int DT>
+int launch_bwd(const AttnArgs& a, hipStream_t st) {
+    constexpr int KS = 32 * DT + 1;
+    const int NP = a.nkt * 32;
+    const size_t lds_kv = sizeof(float) * ((size_t)2 * NP * KS + 2 * (size_t)NP + (size_t)4 * 32 * KS);
+    const size_t lds_q = sizeof(float) * ((size_t)2 * NP * KS + (size_t)4 * 32 * KS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        KV_HIP_CHECK(kv_allow_lds(attn_bwd_kv_kernel<DT>, 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds(attn_bwd_q_kernel<DT>, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<DT>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_kv, st, a);
+    KV_LAUNCH_CHECK("attn_bwd_kv_kernel");
+    hipLaunchKernelGGL((attn_bwd_q_kernel<DT>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_q, st, a);
+    KV_LAUNCH_CHECK("attn_bwd_q_kernel");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, const float* v, float* o, float* lse,
+                    void* stream) {
+    if (int rc = check_desc(d, "kanvit_attn_fwd")) return rc;
+    if (!q || !k || !v || !o) return kv_fail(KANVIT_EINVAL, "kanvit_attn_fwd: null q/k/v/o");
+    if (d->B == 0) return 0;
+    AttnArgs a = make_args(d);
+    a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
+    hipStream_t st = (hipStream_t)stream;
+    return d->D <= 32 ? dispatch_fwd<1>(a, st) : dispatch_fwd<2>(a, st);
+}
+
+size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d) {
+    if (!d || d->B < 0 || d->H < 1 || d->N < 1) return 0;
+    return sizeof(float) * (size_t)d->B * d->H * d->N;
+}
+
+/* dq/dk/dv are fully written (no accumulation into the outputs). */
+int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, const float* v, const float* o,
+                    const float* lse, const float* d_o, float* dq, float* dk, float* dv, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d, "kanvit_attn_bwd")) return rc;
+    if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv)
+        return kv_fail(KANVIT_EINVAL, "kanvit_attn_bwd: null argument");
+    if (d->B == 0) return 0;
+    if (!workspace || workspace_bytes < kanvit_attn_bwd_workspace(d))
+        return kv_fail(KANVIT_ENOMEM, "kanvit_attn_bwd: workspace %zu bytes < required %zu", workspace_bytes,
+                       kanvit_attn_bwd_workspace(d));
+    float* delta_ws = (float*)workspace;
+    AttnArgs a = make_args(d);
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse_in = lse; a.d_o = d_o;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.delta = delta_ws; a.delta_in = delta_ws;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)d->B * d->H * d->N;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
+    KV_LAUNCH_CHECK("attn_delta_kernel");
+    return d->D <= 32 ? launch_bwd<1>(a, st) : launch_bwd<2>(a, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// Device-side basis functions of the five KAN families (+ the identity "linear"
+// family) and their derivatives.  Values are produced straight into an LDS
+// tile (dst[j*stride]); nothing here touches HBM except the small per-group
+// parameter tables (knots / centres / freq / phase), which are L1/L2 resident.
+//
+// Reference arithmetic being restated (paths relative to the reference repo):
+//   CHEBY   models/cheby.py:37-43     T_d(tanh x) = cos(d*acos(tanh x)); evaluated by the
+//                                     three-term recurrence ("Transcendental cost")
+//   BSPLINE models/effkan.py:99-132   Cox-de Boor recursion, half-open order-0 indicator
+//   RBF     models/fastkan.py:29-30   exp(-((u-c)/h)^2);  base path silu(x) fastkan.py:74
+//   SINE    models/sinekan.py:86      sin(x*freq + phase)
+//   FOURIER models/nfkan.py:44-45     cos(k x), sin(k x), k = 1..G (rotation recurrence)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define KV_LINEAR 0
+#define KV_CHEBY 1
+#define KV_BSPLINE 2
+#define KV_RBF 3
+#define KV_SINE 4
+#define KV_FOURIER 5
+
+#define KV_MAX_KNOTS 40   // generic B-spline path: grid_size + 2*order + 1 <= 40
+
+struct BasisArgs {
+    int G;             // family count parameter (see kanvit.h)
+    int GP;            // generated columns per input feature
+    int order;         // BSPLINE
+    int nk;            // BSPLINE knots per feature
+    int has_base;      // BSPLINE / RBF
+    float inv_h;       // RBF
+    const float* bp;   // this group's parameter table
+};
+
+__device__ __forceinline__ float kv_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float kv_dsilu(float x) {
+    const float s = 1.0f / (1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------------------------
+// B-spline helpers.  Both run the Cox-de Boor recursion up to order-1, then finish the last
+// level producing values and (optionally) derivatives in one pass:
+//   dB_{j,p}/dx = p*(B_{j,p-1}/(t_{j+p}-t_j) - B_{j+1,p-1}/(t_{j+p+1}-t_{j+1}))
+// _fixed: compile-time knot count / order, fully unrolled, everything in registers (the
+//         grid_size=5, spline_order=3 configuration of every reference call site);
+// _rt:    runtime sizes, local arrays (slow path for other ctor arguments).
+// ---------------------------------------------------------------------------------------------
+template <int NK, int ORD, bool DER>
+__device__ __forceinline__ void kv_bspline_fixed(const float* __restrict__ kn_g, float xv, float* __restrict__ val,
+                                                 float* __restrict__ der) {
+    float kn[NK];
+    float bb[NK - 1];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kn[j] = kn_g[j];
+#pragma unroll
+    for (int j = 0; j < NK - 1; ++j) bb[j] = (xv >= kn[j] && xv < kn[j + 1]) ? 1.0f : 0.0f;   // effkan.py:115
+#pragma unroll
+    for (int k = 1; k < ORD; ++k) {
+#pragma unroll
+        for (int j = 0; j < NK - 1 - k; ++j) {
+            const float l = __fdividef(xv - kn[j], kn[j + k] - kn[j]);
+            const float r = __fdividef(kn[j + k + 1] - xv, kn[j + k + 1] - kn[j + 1]);
+            bb[j] = l * bb[j] + r * bb[j + 1];                                                  // effkan.py:117-125
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NK - 1 - ORD; ++j) {
+        const float il = __fdividef(1.0f, kn[j + ORD] - kn[j]);
+        const float ir = __fdividef(1.0f, kn[j + ORD + 1] - kn[j + 1]);
+        val[j] = (xv - kn[j]) * il * bb[j] + (kn[j + ORD + 1] - xv) * ir * bb[j + 1];
+        if (DER) der[j] = (float)ORD * (bb[j] * il - bb[j + 1] * ir);
+    }
+}
+
+__device__ __noinline__ void kv_bspline_rt(const float* __restrict__ kn, int nk, int ord, float xv,
+                                           float* __restrict__ val, float* __restrict__ der) {
+    float bb[KV_MAX_KNOTS];
+    for (int j = 0; j < nk - 1; ++j) bb[j] = (xv >= kn[j] && xv < kn[j + 1]) ? 1.0f : 0.0f;
+    for (int k = 1; k < ord; ++k)
+        for (int j = 0; j < nk - 1 - k; ++j) {
+            const float l = __fdividef(xv - kn[j], kn[j + k] - kn[j]);
+            const float r = __fdividef(kn[j + k + 1] - xv, kn[j + k + 1] - kn[j + 1]);
+            bb[j] = l * bb[j] + r * bb[j + 1];
+        }
+    if (ord == 0) {
+        for (int j = 0; j < nk - 1; ++j) {
+            val[j] = bb[j];
+            if (der) der[j] = 0.0f;
+        }
+        return;
+    }
+    for (int j = 0; j < nk - 1 - ord; ++j) {
+        const float il = __fdividef(1.0f, kn[j + ord] - kn[j]);
+        const float ir = __fdividef(1.0f, kn[j + ord + 1] - kn[j + 1]);
+        val[j] = (xv - kn[j]) * il * bb[j] + (kn[j + ord + 1] - xv) * ir * bb[j + 1];
+        if (der) der[j] = (float)ord * (bb[j] * il - bb[j + 1] * ir);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: write GP values for feature i (value xv; RBF spline path uses uv) to dst[j*stride]
+// ---------------------------------------------------------------------------------------------
+template <int FAM>
+__device__ __forceinline__ void basis_fwd(const BasisArgs& b, float xv, float uv, int i, float* __restrict__ dst,
+                                          int stride) {
+    if constexpr (FAM == KV_LINEAR) {
+        dst[0] = xv;
+    } else if constexpr (FAM == KV_CHEBY) {
+        const float t = tanhf(xv);
+        float p0 = 1.0f, p1 = t;
+        dst[0] = 1.0f;
+        if (b.G > 1) dst[stride] = t;
+        for (int g = 2; g < b.G; ++g) {
+            const float p2 = 2.0f * t * p1 - p0;
+            dst[g * stride] = p2;
+            p0 = p1;
+            p1 = p2;
+        }
+    } else if constexpr (FAM == KV_BSPLINE) {
+        const float* kn = b.bp + (long long)i * b.nk;
+        if (b.nk == 12 && b.order == 3) {          // grid_size 5, spline_order 3: every call site of the reference
+            float val[8];
+            kv_bspline_fixed<12, 3, false>(kn, xv, val, nullptr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j * stride] = val[j];
+        } else {
+            float val[KV_MAX_KNOTS];
+            kv_bspline_rt(kn, b.nk, b.order, xv, val, nullptr);
+            for (int j = 0; j < b.G; ++j) dst[j * stride] = val[j];
+        }
+        if (b.has_base) dst[b.G * stride] = kv_silu(xv);
+    } else if constexpr (FAM == KV_RBF) {
+        for (int g = 0; g < b.G; ++g) {
+            const float d = (uv - b.bp[g]) * b.inv_h;
+            dst[g * stride] = __expf(-d * d);
+        }
+        if (b.has_base) dst[b.G * stride] = kv_silu(xv);
+    } else if constexpr (FAM == KV_SINE) {
+        const float* fr = b.bp;
+        const float* ph = b.bp + b.G + (long long)i * b.G;
+        for (int g = 0; g < b.G; ++g) dst[g * stride] = sinf(__fadd_rn(__fmul_rn(xv, fr[g]), ph[g]));
+    } else if constexpr (FAM == KV_FOURIER) {
+        float s1, c1;
+        sincosf(xv, &s1, &c1);
+        float ck = c1, sk = s1;
+        for (int k = 0; k < b.G; ++k) {
+            dst[k * stride] = ck;
+            dst[(b.G + k) * stride] = sk;
+            const float cn = ck * c1 - sk * s1;
+            sk = sk * c1 + ck * s1;
+            ck = cn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: dA[j*stride] = d loss / d phi_j for this (row, feature).  Returns d loss / d x in dx
+// and (RBF only) d loss / d u in du.  SINE: dfreq[g] (LDS, one slot per wave, owned by the
+// calling wave) accumulates d loss / d freq_g through a wave reduction -- deterministic order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float kv_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int FAM>
+__device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv, int i, bool valid,
+                                          const float* __restrict__ dA, int stride, float& dx, float& du,
+                                          float* __restrict__ dfreq_wave) {
+    dx = 0.0f;
+    du = 0.0f;
+    if constexpr (FAM == KV_LINEAR) {
+        dx = dA[0];
+    } else if constexpr (FAM == KV_CHEBY) {
+        const float t = tanhf(xv);
+        float u0 = 1.0f, u1 = 2.0f * t;   // U_0, U_1 (second kind): dT_g/dt = g*U_{g-1}
+        float acc = (b.G > 1) ? dA[stride] : 0.0f;
+        for (int g = 2; g < b.G; ++g) {
+            acc += dA[g * stride] * ((float)g * u1);
+            const float u2 = 2.0f * t * u1 - u0;
+            u0 = u1;
+            u1 = u2;
+        }
+        dx = acc * (1.0f - t * t);
+    } else if constexpr (FAM == KV_BSPLINE) {
+        const float* kn = b.bp + (long long)i * b.nk;
+        float acc = 0.0f;
+        if (b.nk == 12 && b.order == 3) {
+            float val[8], der[8];
+            kv_bspline_fixed<12, 3, true>(kn, xv, val, der);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += dA[j * stride] * der[j];
+        } else {
+            float val[KV_MAX_KNOTS], der[KV_MAX_KNOTS];
+            kv_bspline_rt(kn, b.nk, b.order, xv, val, der);
+            for (int j = 0; j < b.G; ++j) acc += dA[j * stride] * der[j];
+        }
+        if (b.has_base) acc += dA[b.G * stride] * kv_dsilu(xv);
+        dx = acc;
+    } else if constexpr (FAM == KV_RBF) {
+        float acc = 0.0f;
+        for (int g = 0; g < b.G; ++g) {
+            const float d = (uv - b.bp[g]) * b.inv_h;
+            acc += dA[g * stride] * (__expf(-d * d) * (-2.0f * d * b.inv_h));
+        }
+        du = acc;
+        if (b.has_base) dx = dA[b.G * stride] * kv_dsilu(xv);
+    } else if constexpr (FAM == KV_SINE) {
+        const float* fr = b.bp;
+        const float* ph = b.bp + b.G + (long long)i * b.G;
+        float acc = 0.0f;
+        for (int g = 0; g < b.G; ++g) {
+            const float f = fr[g];
+            const float c = cosf(__fadd_rn(__fmul_rn(xv, f), ph[g]));
+            const float da = valid ? dA[g * stride] : 0.0f;
+            acc += da * c * f;
+            const float part = kv_wave_sum(da * c * xv);     // all 64 lanes take part (uniform trip count)
+            if ((threadIdx.x & 63) == 0) dfreq_wave[g] += part;
+        }
+        dx = acc;
+    } else if constexpr (FAM == KV_FOURIER) {
+        float s1, c1;
+        sincosf(xv, &s1, &c1);
+        float ck = c1, sk = s1, acc = 0.0f;
+        for (int k = 0; k < b.G; ++k) {
+            const float kf = (float)(k + 1);
+            acc += kf * (dA[(b.G + k) * stride] * ck - dA[k * stride] * sk);   // d cos = -k sin, d sin = k cos
+            const float cn = ck * c1 - sk * s1;
+            sk = sk * c1 + ck * s1;
+            ck = cn;
+        }
+        dx = acc;
+    }
+}

@@ -1,0 +1,88 @@
+"""ctypes binding of libkanvit.so (the C ABI declared in include/kanvit.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails the caller gets
+an exception -- the product path never silently runs on the CPU or on stock torch ops.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkanvit.so")
+
+LINEAR, CHEBY, BSPLINE, RBF, SINE, FOURIER = range(6)
+FAMILY_NAMES = ["linear", "cheby", "bspline", "rbf", "sine", "fourier"]
+
+
+class KanvitError(RuntimeError):
+    pass
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("family", C.c_int32), ("groups", C.c_int32), ("x_group_mod", C.c_int32), ("I", C.c_int32),
+                ("O", C.c_int32), ("G", C.c_int32), ("spline_order", C.c_int32), ("has_base", C.c_int32),
+                ("rbf_inv_h", C.c_float), ("reserved", C.c_int32), ("M", C.c_int64), ("ldx", C.c_int64),
+                ("ldu", C.c_int64), ("ldy", C.c_int64), ("bparam_stride", C.c_int64)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("causal", C.c_int32),
+                ("scale", C.c_float),
+                ("q_stride_b", C.c_int64), ("q_stride_h", C.c_int64), ("q_stride_n", C.c_int64),
+                ("k_stride_b", C.c_int64), ("k_stride_h", C.c_int64), ("k_stride_n", C.c_int64),
+                ("v_stride_b", C.c_int64), ("v_stride_h", C.c_int64), ("v_stride_n", C.c_int64),
+                ("o_stride_b", C.c_int64), ("o_stride_h", C.c_int64), ("o_stride_n", C.c_int64)]
+
+
+_P = C.c_void_p
+_LAYER_FWD = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P]
+_LAYER_BWD_IN = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]
+_LAYER_BWD_W = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]
+
+# every symbol include/kanvit.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "kanvit_abi_version": (C.c_int, []),
+    "kanvit_last_error": (C.c_char_p, []),
+    "kanvit_device_count": (C.c_int, []),
+    "kanvit_layer_fwd": (C.c_int, _LAYER_FWD),
+    "kanvit_layer_bwd_input": (C.c_int, _LAYER_BWD_IN),
+    "kanvit_layer_dparam_tiles": (C.c_int64, [C.POINTER(LayerDesc)]),
+    "kanvit_layer_bwd_weight_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
+    "kanvit_layer_bwd_weight": (C.c_int, _LAYER_BWD_W),
+    "kanvit_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
+    "kanvit_attn_bwd_workspace": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "kanvit_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+}
+for _f in FAMILY_NAMES:
+    SYMBOLS[f"kanvit_{_f}_fwd"] = (C.c_int, _LAYER_FWD)
+    SYMBOLS[f"kanvit_{_f}_bwd_input"] = (C.c_int, _LAYER_BWD_IN)
+    SYMBOLS[f"kanvit_{_f}_bwd_weight"] = (C.c_int, _LAYER_BWD_W)
+    SYMBOLS[f"kanvit_{_f}_qkv_fwd"] = (C.c_int, _LAYER_FWD)
+    SYMBOLS[f"kanvit_{_f}_qkv_bwd_input"] = (C.c_int, _LAYER_BWD_IN)
+    SYMBOLS[f"kanvit_{_f}_qkv_bwd_weight"] = (C.c_int, _LAYER_BWD_W)
+
+_lib = None
+
+
+def lib():
+    """Load libkanvit.so once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KanvitError(
+                f"{LIB_PATH} not found: build it with `python kan-vit_amd/kanvit/build.py` "
+                "(or __graft_entry__.build()). The kanvit ops have no CPU / eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)          # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.kanvit_abi_version() != 1:
+            raise KanvitError("libkanvit.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().kanvit_last_error()
+        raise KanvitError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,62 @@
+"""Launch helpers: one fused kernel per KAN layer, or ONE kernel for every head's q, k and v
+mapping of an MSA block (3*H independent layers that share the rows of x).
+
+A layer module takes part by exposing
+    kan_cfg()  -> ops.LayerCfg (groups = 1)
+    kan_pack() -> (w[K, O], bparams[stride] | None, bias[O] | None)   built with differentiable
+                  torch ops from the module's reference-layout parameters, so autograd scatters
+                  the packed-weight gradient back to cheby_coeffs / spline_weight / ... itself
+    kan_u(x2d) -> u | None  (FastKAN: the LayerNorm'ed input of the spline path)
+The packing is O(|W|) plumbing; every flop of the layer itself runs in the HIP kernel.
+"""
+from __future__ import annotations
+
+from dataclasses import replace
+from typing import Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def linear_cfg(lin: torch.nn.Linear) -> ops.LayerCfg:
+    return ops.LayerCfg(family=ops.LINEAR, I=lin.in_features, O=lin.out_features, G=1)
+
+
+def linear_pack(lin: torch.nn.Linear):
+    return lin.weight.t(), None, lin.bias
+
+
+def _cfg_pack(m):
+    if isinstance(m, torch.nn.Linear):
+        return linear_cfg(m), linear_pack(m)
+    return m.kan_cfg(), m.kan_pack()
+
+
+def run_single(layer, x2d: torch.Tensor) -> torch.Tensor:
+    """y[M, O] for one layer on a 2-D input."""
+    cfg, (w, bp, bias) = _cfg_pack(layer)
+    u = layer.kan_u(x2d) if hasattr(layer, "kan_u") else None
+    return ops.kan_layer(x2d, w.unsqueeze(0), cfg, u=u,
+                         bparams=None if bp is None else bp.unsqueeze(0),
+                         bias=None if bias is None else bias.reshape(1, -1))
+
+
+def run_qkv(q_layers: Sequence, k_layers: Sequence, v_layers: Sequence, x2d: torch.Tensor) -> torch.Tensor:
+    """x2d[M, H*dh] -> qkv[M, 3*H*dh]; column block g = proj*H + head holds layer g's output.
+
+    Equivalent to the reference's per-sample, per-head loop (attention.py:188-197) because every
+    layer acts row-wise."""
+    H = len(q_layers)
+    layers = list(q_layers) + list(k_layers) + list(v_layers)
+    cfg0, _ = _cfg_pack(layers[0])
+    packs = [_cfg_pack(m)[1] for m in layers]
+    cfg = replace(cfg0, groups=3 * H, x_group_mod=H)
+    w = torch.stack([p[0] for p in packs], dim=0)
+    bp = None if packs[0][1] is None else torch.stack([p[1] for p in packs], dim=0)
+    bias = None if packs[0][2] is None else torch.stack([p[2] for p in packs], dim=0)
+    u = None
+    if hasattr(layers[0], "kan_u_grouped"):
+        u = type(layers[0]).kan_u_grouped(layers, x2d, H)
+    return ops.kan_layer(x2d, w, cfg, u=u, bparams=bp, bias=bias)

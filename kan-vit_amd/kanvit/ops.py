@@ -1,0 +1,233 @@
+"""torch.autograd wrappers around the kanvit C ABI (include/kanvit.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and the autograd tape.
+All arithmetic of the hot path (basis evaluation, contractions, attention) runs in the HIP
+kernels of libkanvit.so.  There is no fallback: CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BSPLINE, CHEBY, FOURIER, LINEAR, RBF, SINE, AttnDesc, KanvitError, LayerDesc, check  # noqa: F401
+
+
+@dataclass(frozen=True)
+class LayerCfg:
+    """Static description of one (grouped) fused KAN layer launch; mirrors kanvit_layer_desc."""
+    family: int
+    I: int
+    O: int
+    G: int
+    groups: int = 1
+    x_group_mod: int = 1
+    spline_order: int = 0
+    has_base: int = 0
+    rbf_inv_h: float = 0.0
+
+    @property
+    def GP(self) -> int:
+        return {LINEAR: 1, CHEBY: self.G, BSPLINE: self.G + self.has_base, RBF: self.G + self.has_base,
+                SINE: self.G, FOURIER: 2 * self.G}[self.family]
+
+    @property
+    def K(self) -> int:
+        return self.I * self.GP
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu_f32(name: str, t: Optional[torch.Tensor]):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise KanvitError(f"{name} is on {t.device}: the kanvit ops run only on an AMD GPU (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise KanvitError(f"{name} has dtype {t.dtype}; the kanvit kernels compute in float32")
+
+
+def _desc(cfg: LayerCfg, M: int, ldx: int, ldu: int, ldy: int, bp_stride: int) -> LayerDesc:
+    return LayerDesc(cfg.family, cfg.groups, cfg.x_group_mod, cfg.I, cfg.O, cfg.G, cfg.spline_order, cfg.has_base,
+                     cfg.rbf_inv_h, 0, M, ldx, ldu, ldy, bp_stride)
+
+
+class _KanLayerFn(torch.autograd.Function):
+    """y[M, groups*O] = fused_kan(x[M, x_group_mod*I], u, w[groups, K, O], bparams, bias)."""
+
+    @staticmethod
+    def forward(ctx, x, u, w, bparams, bias, cfg: LayerCfg):
+        for n, t in (("x", x), ("u", u), ("w", w), ("bparams", bparams), ("bias", bias)):
+            _require_gpu_f32(n, t)
+        x = x.contiguous()
+        w = w.contiguous()
+        u = None if u is None else u.contiguous()
+        bparams = None if bparams is None else bparams.contiguous()
+        bias = None if bias is None else bias.contiguous()
+        M, ldx = x.shape
+        if ldx != cfg.x_group_mod * cfg.I:
+            raise KanvitError(f"x has {ldx} columns, expected x_group_mod*I = {cfg.x_group_mod * cfg.I}")
+        if tuple(w.shape) != (cfg.groups, cfg.K, cfg.O):
+            raise KanvitError(f"packed weight shape {tuple(w.shape)} != {(cfg.groups, cfg.K, cfg.O)}")
+        if u is not None and tuple(u.shape) != (M, cfg.groups * cfg.I):
+            raise KanvitError(f"u shape {tuple(u.shape)} != {(M, cfg.groups * cfg.I)}")
+        y = torch.empty(M, cfg.groups * cfg.O, device=x.device, dtype=torch.float32)
+        d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, 0 if bparams is None else bparams.shape[1])
+        with torch.cuda.device(x.device):
+            check(_lib.lib().kanvit_layer_fwd(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(bias),
+                                              _ptr(y), _stream()), "kanvit_layer_fwd")
+        ctx.cfg = cfg
+        ctx.has_u = u is not None
+        ctx.has_bp = bparams is not None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, u, w, bparams)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg: LayerCfg = ctx.cfg
+        x, u, w, bparams = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, ldx = x.shape
+        need_x, need_u, need_w, need_bp, need_b = ctx.needs_input_grad[:5]
+        d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, 0 if bparams is None else bparams.shape[1])
+        L = _lib.lib()
+        dx = du = dw = dbp = db = None
+        sine_freq = cfg.family == SINE and need_bp
+        with torch.cuda.device(x.device):
+            if need_x or (need_u and ctx.has_u) or sine_freq:
+                dx = torch.empty_like(x)
+                du_buf = torch.empty(M, cfg.groups * cfg.I, device=x.device, dtype=torch.float32) if cfg.family == RBF else None
+                dpart = None
+                if cfg.family == SINE:
+                    tiles = int(L.kanvit_layer_dparam_tiles(C.byref(d)))
+                    dpart = torch.empty(tiles, cfg.groups, cfg.G, device=x.device, dtype=torch.float32)
+                check(L.kanvit_layer_bwd_input(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(dy), _ptr(dx),
+                                               _ptr(du_buf), _ptr(dpart), _stream()), "kanvit_layer_bwd_input")
+                if cfg.family == RBF:
+                    if ctx.has_u:
+                        du = du_buf
+                    else:   # u aliased x (no LayerNorm): fold the spline-path gradient back into dx
+                        nshare = cfg.groups // cfg.x_group_mod
+                        dx = dx + du_buf.view(M, nshare, cfg.x_group_mod * cfg.I).sum(1)
+                if sine_freq:
+                    dbp = torch.zeros_like(bparams)
+                    dbp[:, :cfg.G] = dpart.sum(0)
+            if need_w:
+                dw = torch.empty_like(w)
+                nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(d)))
+                ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+                check(L.kanvit_layer_bwd_weight(C.byref(d), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(dw),
+                                                _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
+            if need_b and ctx.has_bias:
+                db = dy.view(M, cfg.groups, cfg.O).sum(0)
+        return (dx if need_x else None), (du if need_u else None), dw, dbp, db, None
+
+
+def kan_layer(x: torch.Tensor, w: torch.Tensor, cfg: LayerCfg, u: Optional[torch.Tensor] = None,
+              bparams: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused basis + contraction for `cfg.groups` layers sharing the rows of x (see include/kanvit.h)."""
+    return _KanLayerFn.apply(x, u, w, bparams, bias, cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_desc(q, k, v, o, causal: bool, scale: float) -> AttnDesc:
+    B, H, N, D = q.shape
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        if t.stride(3) != 1:
+            raise KanvitError(f"{n}: innermost dimension must be contiguous")
+    return AttnDesc(B, H, N, D, int(bool(causal)), float(scale),
+                    q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                    v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2))
+
+
+def _attn_fwd(q, k, v, o, causal, scale):
+    B, H, N, _ = q.shape
+    lse = torch.empty(B, H, N, device=q.device, dtype=torch.float32)
+    d = _attn_desc(q, k, v, o, causal, scale)
+    with torch.cuda.device(q.device):
+        check(_lib.lib().kanvit_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()),
+              "kanvit_attn_fwd")
+    return lse
+
+
+def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale):
+    d = _attn_desc(q, k, v, o, causal, scale)
+    if (do.stride() != o.stride()) or dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != v.stride():
+        raise KanvitError("attention backward: gradient layouts must match their forward tensors")
+    L = _lib.lib()
+    nbytes = int(L.kanvit_attn_bwd_workspace(C.byref(d)))
+    ws = torch.empty(max(nbytes // 4, 1), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        check(L.kanvit_attn_bwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(do), _ptr(dq), _ptr(dk),
+                                _ptr(dv), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_attn_bwd")
+
+
+class _AttnPackedFn(torch.autograd.Function):
+    """qkv[B, N, 3, H, D] (the layout the grouped q|k|v KAN launch writes) -> o[B, N, H*D]."""
+
+    @staticmethod
+    def forward(ctx, qkv, causal: bool, scale: float):
+        _require_gpu_f32("qkv", qkv)
+        qkv = qkv.contiguous()
+        B, N, three, H, D = qkv.shape
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        o = torch.empty(B, N, H, D, device=qkv.device, dtype=torch.float32)
+        lse = _attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal, scale)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.causal, ctx.scale = causal, scale
+        return o.view(B, N, H * D)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, N, _, H, D = qkv.shape
+        do = do.contiguous().view(B, N, H, D)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        _attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do.permute(0, 2, 1, 3), dq, dk, dv, ctx.causal, ctx.scale)
+        return dqkv, None, None
+
+
+class _AttnFn(torch.autograd.Function):
+    """Separate q, k, v of shape (B, H, N, D) with arbitrary outer strides -> o (B, H, N, D)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal: bool, scale: float):
+        for n, t in (("q", q), ("k", k), ("v", v)):
+            _require_gpu_f32(n, t)
+        q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
+        o = torch.empty(q.shape, device=q.device, dtype=torch.float32)
+        lse = _attn_fwd(q, k, v, o, causal, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.causal, ctx.scale = causal, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = do.contiguous()
+        dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
+        _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, ctx.causal, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+def attention_packed(qkv: torch.Tensor, causal: bool = False, scale: Optional[float] = None) -> torch.Tensor:
+    return _AttnPackedFn.apply(qkv, causal, qkv.shape[-1] ** -0.5 if scale is None else scale)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False,
+              scale: Optional[float] = None) -> torch.Tensor:
+    return _AttnFn.apply(q, k, v, causal, q.shape[-1] ** -0.5 if scale is None else scale)

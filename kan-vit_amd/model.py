@@ -1,0 +1,104 @@
+"""VisionTransformer / TransformerBlock -- drop-ins for the reference's model.py:14-169.
+
+Same constructor, same state_dict keys; the KAN patch embedding and the per-head KAN q/k/v
+mappings + attention run in the HIP kernels (through models/*.py and attention.py).  The
+feed-forward block and the LayerNorms are stock dense ops (hipBLASLt / MIOpen through torch) --
+they are not KAN kernels."""
+import torch
+import torch.nn as nn
+
+from attention import MSA, FlashAttention
+from models.cheby import ChebyKANLayer
+from models.effkan import KANLinear
+from models.fastkan import FastKANLayer
+from models.nfkan import NaiveFourierKANLayer
+from models.sinekan import SineKANLayer
+
+
+class TransformerBlock(nn.Module):
+    """x + MSA(LN(x)), then x + FF(LN(x)) (model.py:31-37)."""
+
+    def __init__(self, d_model, n_heads, feedforward_dim=128, attn_type="vanilla"):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(d_model)
+        self.attn = MSA(d_model, n_heads, type=attn_type)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.ff = nn.Sequential(nn.Linear(d_model, feedforward_dim), nn.ReLU(inplace=True),
+                                nn.Linear(feedforward_dim, d_model))
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.ff(self.norm2(x))
+
+
+def _patch_embedding(kind, in_dim, d):
+    if kind in ("vanilla", "flash-attn"):
+        return nn.Linear(in_dim, d)
+    if kind == "efficientkan":
+        return KANLinear(in_dim, d)
+    if kind == "sine":
+        return SineKANLayer(in_dim, d, grid_size=28)
+    if kind == "fourier":
+        return NaiveFourierKANLayer(in_dim, d, grid_size=28)     # works here; crashes in the reference (D4)
+    if kind == "cheby":
+        return ChebyKANLayer(in_dim, d, 4)
+    if kind == "fast":
+        return FastKANLayer(in_dim, d)
+    raise ValueError(f"Unknown transformer type: {kind}")
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, chw, n_patches=7, n_blocks=4, d_hidden=64, n_heads=2, out_d=10, type: str = "vanilla"):
+        super().__init__()
+        self.chw = chw
+        self.n_patches = n_patches
+        self.n_blocks = n_blocks
+        self.n_heads = n_heads
+        self.d_hidden = d_hidden
+        assert chw[1] % n_patches == 0
+        assert chw[2] % n_patches == 0
+        self.patch_size = (chw[1] // n_patches, chw[2] // n_patches)
+        self.input_d = int(chw[0] * self.patch_size[0] * self.patch_size[1])
+
+        self.linear_mapper = _patch_embedding(type, self.input_d, d_hidden)
+        self.v_class = nn.Parameter(torch.randn(1, d_hidden))
+        self.register_buffer('pos_embeddings', self.positional_embeddings(n_patches ** 2 + 1, d_hidden),
+                             persistent=False)
+        if type == "flash-attn":
+            self.blocks = nn.ModuleList([FlashAttention(dim=d_hidden, heads=n_heads) for _ in range(n_blocks)])
+        else:
+            self.blocks = nn.ModuleList([TransformerBlock(d_hidden, n_heads, feedforward_dim=4 * d_hidden,
+                                                          attn_type=type) for _ in range(n_blocks)])
+        self.mlp_head = nn.Sequential(nn.LayerNorm(d_hidden), nn.Linear(d_hidden, out_d))
+
+    def patchify(self, images, n_patches):
+        """(B, C, H, W) -> (B, n_patches^2, C*ph*pw): patches row-major, each flattened in (C, ph, pw)
+        order -- one strided view + copy instead of the reference's n_patches^2 slice copies
+        (model.py:111-126)."""
+        b, c, h, w = images.shape
+        ph, pw = h // n_patches, w // n_patches
+        t = images.reshape(b, c, n_patches, ph, n_patches, pw).permute(0, 2, 4, 1, 3, 5)
+        return t.reshape(b, n_patches * n_patches, c * ph * pw)
+
+    def positional_embeddings(self, seq_length, d):
+        """pe[i, j] = sin(i / 10000^(j/d)) for even j, cos(...) for odd j, evaluated in float64 and
+        stored as float32 (the values of model.py:128-140, without its O(N*d) python loop)."""
+        i = torch.arange(seq_length, dtype=torch.float64).unsqueeze(1)
+        j = torch.arange(d, dtype=torch.float64).unsqueeze(0)
+        ang = i / torch.pow(torch.tensor(10000.0, dtype=torch.float64), j / d)
+        even = (torch.arange(d) % 2 == 0).unsqueeze(0)
+        return torch.where(even, torch.sin(ang), torch.cos(ang)).to(torch.float32)
+
+    def forward(self, images):
+        patches = self.patchify(images, self.n_patches)
+        b, p, _ = patches.shape
+        if isinstance(self.linear_mapper, nn.Linear):
+            tokens = self.linear_mapper(patches)
+        else:
+            # ChebyKANLayer returns (B*P, d) like the reference's; restore (B, P, d)
+            tokens = self.linear_mapper(patches).reshape(b, p, self.d_hidden)
+        cls = self.v_class.unsqueeze(0).expand(b, -1, -1)
+        out = torch.cat((cls, tokens), dim=1) + self.pos_embeddings[: p + 1]
+        for blk in self.blocks:
+            out = blk(out)
+        return self.mlp_head(out[:, 0])

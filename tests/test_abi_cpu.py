@@ -1,0 +1,141 @@
+"""CPU-only checks of the boundary: the C-ABI library builds/loads and exports every symbol
+include/kanvit.h declares, descriptors have the C layout, the drop-in modules keep the reference's
+state_dict layout, and the product path refuses to run without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import T, load_npz, max_err, state_dict_from
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from kanvit import build
+    build.build(verbose=False)
+    from kanvit import _lib
+    return _lib.lib()
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "kanvit.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(kanvit_[a-z0-9_]+)\s*\(", src))
+    fams = re.findall(r"KANVIT_DECLARE_FAMILY\((\w+)\)", src)
+    names = {n for n in names if "##" not in n}
+    for f in fams:
+        if f == "name":
+            continue
+        for suf in ("fwd", "bwd_input", "bwd_weight", "qkv_fwd", "qkv_bwd_input", "qkv_bwd_weight"):
+            names.add(f"kanvit_{f}_{suf}")
+    return names
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from kanvit import _lib
+    declared = _declared_functions()
+    assert len(declared) >= 11 + 36
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in kanvit.h but not exported"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+def test_descriptor_layout_and_errors(lib):
+    from kanvit import _lib
+    assert ctypes.sizeof(_lib.LayerDesc) == 10 * 4 + 5 * 8
+    assert ctypes.sizeof(_lib.AttnDesc) == 6 * 4 + 12 * 8
+    assert lib.kanvit_abi_version() == 1
+    d = _lib.LayerDesc(family=99, groups=1, x_group_mod=1, I=4, O=3, G=1, M=6, ldx=4, ldy=3)
+    rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
+    assert rc == -22 and b"family" in lib.kanvit_last_error()
+    d.family = _lib.CHEBY
+    d.G = 5
+    rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
+    assert rc == -22 and b"null" in lib.kanvit_last_error()
+    d.G = 100
+    assert lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -22
+    d.G = 5
+    assert lib.kanvit_cheby_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -22
+    assert lib.kanvit_sine_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -22
+    assert b"mismatch" in lib.kanvit_last_error()
+    # workspace sizing is a pure host function
+    d.M, d.I, d.O, d.groups, d.x_group_mod, d.ldx, d.ldy = 25216, 64, 64, 36, 12, 768, 2304
+    ws = lib.kanvit_layer_bwd_weight_workspace(ctypes.byref(d))
+    assert ws % (36 * 320 * 64 * 4) == 0 and ws > 0
+    a = _lib.AttnDesc(B=2, H=3, N=300, D=64, scale=0.125)
+    assert lib.kanvit_attn_fwd(ctypes.byref(a), None, None, None, None, None, None) == -22
+    a.N, a.D = 197, 63
+    assert lib.kanvit_attn_fwd(ctypes.byref(a), None, None, None, None, None, None) == -22
+    a.D = 64
+    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == 2 * 3 * 197 * 4
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must raise; nothing may quietly compute on the host."""
+    from kanvit import KanvitError
+    from models.cheby import ChebyKANLayer
+    layer = ChebyKANLayer(4, 3, 4)
+    with pytest.raises(KanvitError):
+        layer(torch.randn(6, 4))
+    from attention import MSA
+    with pytest.raises(KanvitError):
+        MSA(64, 2, type="vanilla")(torch.randn(2, 5, 64))
+
+
+TYPES = ["vanilla", "flash-attn", "efficientkan", "sine", "fourier", "cheby", "fast"]
+
+
+@pytest.mark.parametrize("geom", ["T", "C"])
+@pytest.mark.parametrize("t", TYPES)
+def test_reference_state_dict_loads(geom, t):
+    """Keys / shapes of the drop-in modules equal the reference's (strict load of its state dict)."""
+    from model import VisionTransformer
+    blob = load_npz(f"model_{geom}_{t}.npz")
+    c, h, w, npatch, nblk, d, heads, out_d = (int(v) for v in blob["cfg"])
+    m = VisionTransformer((c, h, w), npatch, nblk, d, heads, out_d, type=t)
+    sd = state_dict_from(blob)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert "pos_embeddings" not in m.state_dict()           # persistent=False like model.py:86-90
+
+
+def test_host_helpers_match_reference():
+    from model import VisionTransformer
+    m = load_npz("misc.npz")
+    vt = VisionTransformer((1, 28, 28), 7, 1, 64, 2, 10, type="vanilla")
+    assert max_err(vt.pos_embeddings, T(m["pos_emb_50_64"])) < 1e-6
+    vt2 = VisionTransformer((3, 8, 8), 2, 1, 16, 2, 10, type="vanilla")
+    assert max_err(vt2.patchify(T(m["patchify_in"]), 2), T(m["patchify_out"])) == 0.0
+    from models.sinekan import SineKANLayer
+    s = SineKANLayer(32, 32, grid_size=4)
+    assert max_err(s.phase, T(m["sine4.phase"])) < 1e-6
+    assert np.allclose(s.freq.detach().reshape(-1).numpy(), [0.2, 0.4, 0.6, 0.8])
+    from models.effkan import KANLinear
+    k = KANLinear(1, 1)
+    assert max_err(k.grid, T(m["bspline.grid"])) == 0.0
+    for name, val in {"x0": 0.0, "x1": 1.0, "xm": -2.3, "xp": 2.2, "xh": 0.37}.items():
+        assert max_err(k.b_splines(torch.tensor([[val]]))[0, 0], T(m["bspline." + name])) < 1e-6
+    from models.fastkan import FastKANLayer
+    f = FastKANLayer(4, 3)
+    assert max_err(f.rbf.grid, T(m["rbf.grid"])) == 0.0 and abs(f.rbf.denominator - 4 / 7) < 1e-12
+
+
+def test_init_statistics_follow_reference():
+    """Initial distributions (not values) follow the reference constructors."""
+    torch.manual_seed(0)
+    from models.cheby import ChebyKANLayer
+    from models.effkan import KANLinear
+    from models.nfkan import NaiveFourierKANLayer
+    c = ChebyKANLayer(64, 64, 4)
+    assert abs(float(c.cheby_coeffs.std()) - 1 / (64 * 5)) < 2e-4
+    f = NaiveFourierKANLayer(16, 64, grid_size=28)
+    assert abs(float(f.fouriercoeffs.std()) - 1 / (4 * 28 ** 0.5)) < 2e-3
+    k = KANLinear(32, 32)
+    assert k.spline_weight.shape == (32, 32, 8) and float(k.spline_weight.abs().max()) < 0.2
+    assert torch.isfinite(k.spline_weight).all()

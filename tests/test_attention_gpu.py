@@ -1,0 +1,89 @@
+"""GPU parity of the attention kernels against the reference's FlashAttentionFunction outputs
+(tests/golden/flash.npz) and the float64 oracle, over sequence lengths / head sizes / layouts."""
+import pytest
+import torch
+
+from oracle import kan_oracle as ko
+from tests._util import T, load_npz, max_err, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_flash_function_against_reference_fixture():
+    from utils import FlashAttentionFunction
+    f = load_npz("flash.npz")
+    q, k, v = (T(f[n]).to(DEV).requires_grad_(True) for n in ("q", "k", "v"))
+    do = T(f["do"]).to(DEV)
+    for tag, causal in (("big", False), ("small", False), ("causal", True)):
+        for t in (q, k, v):
+            t.grad = None
+        o = FlashAttentionFunction.apply(q, k, v, None, causal, 512, 1024)
+        o.backward(do)
+        assert max_err(o.cpu(), T(f[tag + ".o"])) < 5e-6, tag
+        assert max_err(q.grad.cpu(), T(f[tag + ".dq"])) < 2e-5, tag
+        assert max_err(k.grad.cpu(), T(f[tag + ".dk"])) < 2e-5, tag
+        assert max_err(v.grad.cpu(), T(f[tag + ".dv"])) < 2e-5, tag
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 31, 32, 33, 50, 64, 100, 197, 224])
+@pytest.mark.parametrize("d", [2, 8, 32, 64])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_against_oracle(n, d, causal):
+    from kanvit import ops
+    torch.manual_seed(n * 7 + d)
+    b, h = 2, 3
+    q, k, v = (torch.randn(b, h, n, d) * 1.3 for _ in range(3))
+    do = torch.randn(b, h, n, d)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = ko.attention_reference(qd, kd, vd, causal=causal)
+    o_ref.backward(do.double())
+    qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    o = ops.attention(qg, kg, vg, causal=causal)
+    o.backward(do.to(DEV))
+    assert max_err(o.cpu(), o_ref) < 1e-5
+    assert rel_err(qg.grad.cpu(), qd.grad) < 1e-4
+    assert rel_err(kg.grad.cpu(), kd.grad) < 1e-4
+    assert rel_err(vg.grad.cpu(), vd.grad) < 1e-4
+
+
+def test_large_score_spike_is_stable():
+    """One query aligned with one key at a large scale: softmax must not overflow."""
+    from kanvit import ops
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(1, 2, 197, 64) for _ in range(3))
+    q[0, 0, 5] = k[0, 0, 100] * 40.0
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)).cpu()
+    o_ref, _ = ko.attention_reference(q.double(), k.double(), v.double())
+    assert torch.isfinite(o).all() and max_err(o, o_ref) < 1e-4
+
+
+def test_packed_layout_matches_separate():
+    from kanvit import ops
+    torch.manual_seed(1)
+    b, n, h, d = 3, 50, 2, 32
+    qkv = torch.randn(b, n, 3, h, d, device=DEV, requires_grad=True)
+    w = torch.randn(b, n, h * d, device=DEV)
+    o = ops.attention_packed(qkv)
+    (o * w).sum().backward()
+    q, k, v = (qkv.detach()[:, :, i].permute(0, 2, 1, 3).cpu().double().requires_grad_(True) for i in range(3))
+    o_ref, _ = ko.attention_reference(q, k, v)
+    (o_ref.permute(0, 2, 1, 3).reshape(b, n, h * d) * w.cpu().double()).sum().backward()
+    assert max_err(o.cpu(), o_ref.permute(0, 2, 1, 3).reshape(b, n, h * d)) < 1e-5
+    g = qkv.grad.cpu()
+    for i, t in enumerate((q, k, v)):
+        assert rel_err(g[:, :, i].permute(0, 2, 1, 3), t.grad) < 1e-4
+
+
+def test_bitwise_reproducible():
+    from kanvit import ops
+    q, k, v = (torch.randn(4, 12, 197, 64, device=DEV, requires_grad=True) for _ in range(3))
+    res = []
+    for _ in range(2):
+        for t in (q, k, v):
+            t.grad = None
+        o = ops.attention(q, k, v)
+        o.sum().backward()
+        res.append((o.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
