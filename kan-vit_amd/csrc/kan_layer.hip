@@ -617,6 +617,7 @@ int kanvit_device_count(void) {
 int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u, const float* w, const float* bparams,
                      const float* bias, float* y, void* stream) {
     if (int rc = validate(d, "kanvit_layer_fwd")) return rc;
+    if (d->M == 0) return 0;
     if (!x || !w || !y) return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: null x/w/y");
     if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: family %d needs bparams", d->family);
     if (d->family == KANVIT_RBF && u && d->ldu < (int64_t)d->groups * d->I)
@@ -643,6 +644,7 @@ int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d) {
 int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const float* u, const float* w,
                            const float* bparams, const float* dy, float* dx, float* du, float* dparam, void* stream) {
     if (int rc = validate(d, "kanvit_layer_bwd_input")) return rc;
+    if (d->M == 0) return 0;
     if (!x || !w || !dy || !dx) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: null x/w/dy/dx");
     if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: family %d needs bparams", d->family);
     if (d->family == KANVIT_SINE && !dparam) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: SINE needs dparam");
@@ -676,6 +678,11 @@ size_t kanvit_layer_bwd_weight_workspace(const kanvit_layer_desc* d) {
 int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const float* u, const float* bparams,
                             const float* dy, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = validate(d, "kanvit_layer_bwd_weight")) return rc;
+    if (d->M == 0) {   // no rows: the gradient is exactly zero
+        if (!dw) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: null dw");
+        KV_HIP_CHECK(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->groups * d->I * gp_of(d) * d->O, (hipStream_t)stream));
+        return 0;
+    }
     if (!x || !dy || !dw) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: null x/dy/dw");
     if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: family %d needs bparams", d->family);
     if (d->family == KANVIT_RBF && u && d->ldu < (int64_t)d->groups * d->I)

@@ -6,6 +6,12 @@ an exception -- the product path never silently runs on the CPU or on stock torc
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be
+# in the process BEFORE libkanvit.so is dlopen'ed so that our DT_NEEDED libamdhip64.so.7 binds to
+# that same runtime (streams and device pointers are only meaningful inside one runtime instance);
+# loading ours first would pull /opt/rocm's copy in and leave the process with two runtimes.
+import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkanvit.so")
 

@@ -45,3 +45,9 @@ def rel_err(a, b, floor=1e-3):
     softmax attention, which is shift invariant) from being compared noise-to-noise."""
     a, b = a.detach().double(), b.detach().double()
     return float((a - b).abs().max() / max(float(b.abs().max()), floor))
+
+
+def close(a, b, rtol=1e-4, atol=2e-6):
+    """max|a-b| <= atol + rtol*max|b| -- for tensors that may be mathematically zero."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) <= atol + rtol * float(b.abs().max())
