@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of a full ViKANformer train step on N MI355X (one process per GPU).
+
+    python bench.py                                   # N=1, default workload, finishes in ~1-2 min
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + CrossEntropy + zero_grad + backward (+ gradient all-reduce when N > 1) +
+Adam.step on one synthetic batch that is already resident in HBM (train.py:31-40 of the
+reference).  Weak scaling: the per-GPU batch is fixed, value = N * batch * K / t.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  roofline      the dominant hand-written kernel: algorithmic flops divided
+                by its average launch time measured live with events on the launch stream
+  kernels       the same for every C-ABI launch class (extra, for DESIGN.md tables)
+  cpu_baseline  the CPU oracle in reference-faithful mode (per-sample x per-head python loop,
+                attention.py:188-202) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "kan-vit_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json metric: "images/sec (train step) KAN-ViT 224x224"; target workload of north_star
+    "vitb16-224-cheby": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="cheby", batch=128),
+    "vits16-224-cheby": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=384, heads=6, out_d=100, type="cheby", batch=256),
+    "vits16-224-fast": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=384, heads=6, out_d=100, type="fast", batch=256),
+    "vitb16-224-efficientkan": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="efficientkan", batch=128),
+    "vitb16-224-sine": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="sine", batch=128),
+    "vitb16-224-fourier": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="fourier", batch=128),
+    # BASELINE.json configs[1]: MNIST-shaped defaults of model.py:49
+    "mnist-cheby-tiny": dict(chw=(1, 28, 28), n_patches=7, n_blocks=4, d=64, heads=2, out_d=10, type="cheby", batch=128),
+    # train.py:18-20 geometry
+    "cifar-cheby-default": dict(chw=(3, 32, 32), n_patches=4, n_blocks=8, d=64, heads=8, out_d=100, type="cheby", batch=128),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(model, wl, target_s=15.0):
+    """Reference-faithful CPU train step (oracle/kan_oracle.py, the checker -- never the product)."""
+    from oracle import kan_oracle as ko
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    n_patches, heads, t = wl["n_patches"], wl["heads"], wl["type"]
+
+    def step(n):
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(n, *wl["chw"], generator=g)
+        y = torch.randint(0, wl["out_d"], (n,), generator=g)
+        t0 = time.perf_counter()
+        ko.train_steps(sd, x, y, n_patches, heads, t, steps=1, faithful_loop=True)
+        return time.perf_counter() - t0
+
+    t1 = step(1)                                    # warm-up + calibration
+    n = int(max(1, min(wl["batch"], target_s / max(t1, 1e-3))))
+    tn = step(n)
+    return {"value": round(n / tn, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 train step (fwd+loss+bwd+Adam) on {n} images of {wl['chw']}, reference-style "
+                      f"per-sample x per-head loop, after a 1-image warm-up step ({t1:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="vitb16-224-cheby", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--bucket-mib", type=float, default=64.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kanvit import dp as kdp
+    from kanvit import ops
+    from model import VisionTransformer
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    torch.manual_seed(0)
+    model = VisionTransformer(wl["chw"], wl["n_patches"], wl["n_blocks"], wl["d"], wl["heads"], wl["out_d"],
+                              type=wl["type"]).to(dev)
+    kdp.broadcast_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    reducer = kdp.GradReducer(model.parameters(), bucket_mib=args.bucket_mib) if world > 1 else None
+    crit = torch.nn.CrossEntropyLoss()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(wl["batch"], *wl["chw"], device=dev, generator=g)
+    y = torch.randint(0, wl["out_d"], (wl["batch"],), device=dev, generator=g)
+
+    def step():
+        loss = crit(model(x), y)
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_timer:
+        ops.timer = ops.KernelTimer()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    kern = ops.timer.summary() if ops.timer is not None else {}
+    ops.timer = None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        out = {
+            "metric": "images/sec (train step) KAN-ViT 224x224" if "224" in args.workload else "images/sec (train step)",
+            "value": round(world * wl["batch"] * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "model_type": wl["type"], "image": list(wl["chw"]),
+                       "n_patches": wl["n_patches"], "n_blocks": wl["n_blocks"], "d_hidden": wl["d"],
+                       "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],
+                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3)", "loss_after": round(final_loss, 4)},
+        }
+        kernels = {}
+        for tag, r in kern.items():
+            tf = r["flops"] / (r["avg_ms"] * 1e-3) / 1e12
+            gb = r["bytes"] / (r["avg_ms"] * 1e-3) / 1e9
+            kernels[tag] = {"launches_per_step": r["launches"] / args.steps, "avg_ms": round(r["avg_ms"], 4),
+                            "ms_per_step": round(r["total_ms"] / args.steps, 3), "TFLOP/s": round(tf, 2),
+                            "GB/s": round(gb, 1), "alg_flops": r["flops"], "alg_bytes": r["bytes"]}
+        if kernels:
+            dom = max((t for t in kernels if t.startswith(("qkv", "layer"))), key=lambda t: kernels[t]["ms_per_step"])
+            k = kernels[dom]
+            ai = k["alg_flops"] / k["alg_bytes"]
+            mfma_bound = ai > PEAK_FP32_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS       # ridge of the fp32 matrix pipe
+            if mfma_bound:
+                out["roofline"] = {"bound": "mfma", "achieved": k["TFLOP/s"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(k["TFLOP/s"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "traffic": None}
+            else:
+                out["roofline"] = {"bound": "hbm", "achieved": k["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(k["GB/s"] / PEAK_HBM_GBS, 4), "traffic": None}
+            out["roofline"].update({"kernel": dom, "avg_launch_ms": k["avg_ms"], "arith_intensity_flop_per_byte": round(ai, 1),
+                                    "hbm_GB/s": k["GB/s"], "hbm_frac": round(k["GB/s"] / PEAK_HBM_GBS, 4)})
+            out["kernels"] = kernels
+            out["custom_kernel_ms_per_step"] = round(sum(v["ms_per_step"] for v in kernels.values()), 3)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,56 @@ class LayerCfg:
         return self.I * self.GP
 
 
+class KernelTimer:
+    """Optional in-stream timing of the C-ABI launches (bench.py's roofline leg): a pair of events
+    recorded on the launch stream brackets each call, so the measured interval is that launch's
+    kernels only.  Disabled (None) by default; costs nothing then."""
+
+    def __init__(self):
+        self.records = {}          # tag -> list of (start, end, flops, bytes)
+
+    def add(self, tag, start, end, flops, nbytes):
+        self.records.setdefault(tag, []).append((start, end, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            out[tag] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                        "flops": recs[0][2], "bytes": recs[0][3]}
+        return out
+
+
+timer: Optional[KernelTimer] = None
+
+
+class _timed:
+    def __init__(self, tag, flops=0, nbytes=0):
+        self.tag, self.flops, self.nbytes = tag, flops, nbytes
+
+    def __enter__(self):
+        if timer is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if timer is not None:
+            self.e.record()
+            timer.add(self.tag, self.s, self.e, self.flops, self.nbytes)
+        return False
+
+
+def _layer_cost(cfg: "LayerCfg", M: int, kind: str):
+    """Algorithmic flops / HBM bytes of one launch (SURVEY.md section 8d formulas, fp32)."""
+    flops = 2 * M * cfg.K * cfg.O * cfg.groups
+    xb, yb, wb = M * cfg.x_group_mod * cfg.I, M * cfg.groups * cfg.O, cfg.groups * cfg.K * cfg.O
+    nbytes = 4 * {"fwd": xb + yb + wb, "bwd_input": 2 * xb + yb + wb, "bwd_weight": xb + yb + wb}[kind]
+    return flops, nbytes
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -82,7 +132,8 @@ class _KanLayerFn(torch.autograd.Function):
             raise KanvitError(f"u shape {tuple(u.shape)} != {(M, cfg.groups * cfg.I)}")
         y = torch.empty(M, cfg.groups * cfg.O, device=x.device, dtype=torch.float32)
         d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, 0 if bparams is None else bparams.shape[1])
-        with torch.cuda.device(x.device):
+        tag = ("qkv" if cfg.groups > 1 else "layer") + "_fwd"
+        with torch.cuda.device(x.device), _timed(tag, *_layer_cost(cfg, M, "fwd")):
             check(_lib.lib().kanvit_layer_fwd(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(bias),
                                               _ptr(y), _stream()), "kanvit_layer_fwd")
         ctx.cfg = cfg
@@ -111,8 +162,10 @@ class _KanLayerFn(torch.autograd.Function):
                 if cfg.family == SINE:
                     tiles = int(L.kanvit_layer_dparam_tiles(C.byref(d)))
                     dpart = torch.empty(tiles, cfg.groups, cfg.G, device=x.device, dtype=torch.float32)
-                check(L.kanvit_layer_bwd_input(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(dy), _ptr(dx),
-                                               _ptr(du_buf), _ptr(dpart), _stream()), "kanvit_layer_bwd_input")
+                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_input", *_layer_cost(cfg, M, "bwd_input")):
+                    check(L.kanvit_layer_bwd_input(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(dy),
+                                                   _ptr(dx), _ptr(du_buf), _ptr(dpart), _stream()),
+                          "kanvit_layer_bwd_input")
                 if cfg.family == RBF:
                     if ctx.has_u:
                         du = du_buf
@@ -126,8 +179,9 @@ class _KanLayerFn(torch.autograd.Function):
                 dw = torch.empty_like(w)
                 nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(d)))
                 ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-                check(L.kanvit_layer_bwd_weight(C.byref(d), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(dw),
-                                                _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
+                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_weight", *_layer_cost(cfg, M, "bwd_weight")):
+                    check(L.kanvit_layer_bwd_weight(C.byref(d), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(dw),
+                                                    _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
             if need_b and ctx.has_bias:
                 db = dy.view(M, cfg.groups, cfg.O).sum(0)
         return (dx if need_x else None), (du if need_u else None), dw, dbp, db, None
@@ -156,7 +210,8 @@ def _attn_fwd(q, k, v, o, causal, scale):
     B, H, N, _ = q.shape
     lse = torch.empty(B, H, N, device=q.device, dtype=torch.float32)
     d = _attn_desc(q, k, v, o, causal, scale)
-    with torch.cuda.device(q.device):
+    flops, nbytes = 4 * B * H * N * N * q.shape[3], 4 * 4 * B * H * N * q.shape[3]
+    with torch.cuda.device(q.device), _timed("attn_fwd", flops, nbytes):
         check(_lib.lib().kanvit_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()),
               "kanvit_attn_fwd")
     return lse
@@ -169,7 +224,8 @@ def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale):
     L = _lib.lib()
     nbytes = int(L.kanvit_attn_bwd_workspace(C.byref(d)))
     ws = torch.empty(max(nbytes // 4, 1), device=q.device, dtype=torch.float32)
-    with torch.cuda.device(q.device):
+    B, H, N, D = q.shape
+    with torch.cuda.device(q.device), _timed("attn_bwd", 14 * B * H * N * N * D, 4 * 9 * B * H * N * D):
         check(L.kanvit_attn_bwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(do), _ptr(dq), _ptr(dk),
                                 _ptr(dv), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_attn_bwd")
 

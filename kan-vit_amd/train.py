@@ -1,0 +1,153 @@
+"""Training entry point -- drop-in for the reference's train.py (same flags and defaults,
+train.py:87-97; same step order forward -> CE loss -> zero_grad -> backward -> Adam.step,
+train.py:31-40), running on the MI355X kernels, with optional pure data parallelism:
+
+    python train.py --model-type cheby                                 # 1 GPU, CIFAR-100 if torchvision + data exist
+    python train.py --model-type cheby --synthetic --epochs 1          # synthetic stream, no dataset needed
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --dp --synthetic ...
+
+Additions over the reference (none change a default): --synthetic / --image-size / --in-chans /
+--n-patches / --out-d (geometry), --seed, --dp, --steps-per-epoch, --no-step-metrics (keeps the
+per-step metrics on the device instead of the reference's three host syncs per step,
+train.py:37,42-44)."""
+import argparse
+import logging
+import os
+
+import torch
+from torch.optim import Adam
+
+from kanvit import dp as kdp
+from model import VisionTransformer
+from utils import calculate_metrics, save_metrics, setup_logging
+
+
+def synthetic_loader(n_steps, batch, chw, out_d, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    for _ in range(n_steps):
+        yield (torch.randn(batch, *chw, device=device, generator=g),
+               torch.randint(0, out_d, (batch,), device=device, generator=g))
+
+
+def cifar_loaders(batch, rank, world):
+    from torchvision import transforms
+    from torchvision.datasets import CIFAR100
+    norm = transforms.Normalize(mean=[0.5071, 0.4867, 0.4408], std=[0.2675, 0.2565, 0.2761])
+    tr = transforms.Compose([transforms.RandomHorizontalFlip(), transforms.RandomCrop(32, padding=4),
+                             transforms.ToTensor(), norm])
+    te = transforms.Compose([transforms.ToTensor(), norm])
+    train = CIFAR100(root='./cifar100', train=True, download=True, transform=tr)
+    test = CIFAR100(root='./cifar100', train=False, download=True, transform=te)
+    sampler = torch.utils.data.distributed.DistributedSampler(train, world, rank) if world > 1 else None
+    mk = torch.utils.data.DataLoader
+    return (mk(train, batch_size=batch, shuffle=sampler is None, sampler=sampler, num_workers=8, pin_memory=True),
+            mk(test, batch_size=batch, shuffle=False, num_workers=8, pin_memory=True))
+
+
+def main(args):
+    rank, world, local = 0, 1, 0
+    if args.dp:
+        import torch.distributed as dist
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+    device = torch.device(args.device if not args.dp else f"cuda:{local}")
+    if device.type != "cuda":
+        raise SystemExit("this build runs the hot path on the MI355X only; --device must be a cuda device")
+    torch.manual_seed(args.seed)
+    chw = (args.in_chans, args.image_size, args.image_size)
+    model = VisionTransformer(chw, n_patches=args.n_patches, n_blocks=args.n_blocks, d_hidden=args.d_hidden,
+                              n_heads=args.n_heads, out_d=args.out_d, type=args.model_type).to(device)
+    kdp.broadcast_parameters(model)
+    criterion = torch.nn.CrossEntropyLoss()
+    optimizer = Adam(model.parameters(), lr=args.learning_rate)
+    reducer = kdp.GradReducer(model.parameters()) if world > 1 else None
+    metrics_file = setup_logging(args.log_dir) if rank == 0 else None
+    logging.info(f"Using device: {device} ({torch.cuda.get_device_name(device)}), world {world}")
+
+    per_rank = args.batch_size // world if args.dp else args.batch_size
+    test_loader = None
+    for epoch in range(args.epochs):
+        if args.synthetic:
+            loader = synthetic_loader(args.steps_per_epoch, per_rank, chw, args.out_d, device, args.seed + 1000 * epoch + rank)
+            n_batches = args.steps_per_epoch
+        else:
+            loader, test_loader = cifar_loaders(per_rank, rank, world)
+            n_batches = len(loader)
+        model.train()
+        loss_sum = torch.zeros((), device=device)
+        ys, preds, probs = [], [], []
+        for x, y in loader:
+            x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
+            y_hat = model(x)
+            loss = criterion(y_hat, y)
+            if reducer is not None:
+                reducer.zero_grad()
+            else:
+                optimizer.zero_grad()
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            optimizer.step()
+            loss_sum += loss.detach() / n_batches
+            if not args.no_step_metrics:
+                ys.append(y)
+                preds.append(y_hat.argmax(dim=1))
+                probs.append(torch.softmax(y_hat.detach(), dim=1))
+        train_loss = float(loss_sum)                     # one host sync per epoch
+        if rank == 0:
+            logging.info(f"Epoch {epoch + 1}/{args.epochs}\n  Train Loss: {train_loss:.4f}")
+            if ys:
+                acc, bal, f1, auc = calculate_metrics(torch.cat(ys).cpu().numpy(), torch.cat(preds).cpu().numpy(),
+                                                      torch.cat(probs).cpu().numpy(), num_classes=args.out_d)
+                logging.info(f"  Train Accuracy: {acc:.4f}\n  Train Balanced Accuracy: {bal:.4f}\n"
+                             f"  Train F1 Score: {f1:.4f}\n  Train ROC AUC: {auc:.4f}")
+                if epoch == args.epochs - 1:
+                    save_metrics(metrics_file, epoch + 1, "Train", train_loss, acc, bal, f1, auc, flag=0)
+
+    if test_loader is not None and rank == 0:
+        model.eval()
+        with torch.no_grad():
+            tl, ys, preds, probs = 0.0, [], [], []
+            for x, y in test_loader:
+                x, y = x.to(device), y.to(device)
+                y_hat = model(x)
+                tl += float(criterion(y_hat, y)) / len(test_loader)
+                ys.append(y), preds.append(y_hat.argmax(dim=1)), probs.append(torch.softmax(y_hat, dim=1))
+            acc, bal, f1, auc = calculate_metrics(torch.cat(ys).cpu().numpy(), torch.cat(preds).cpu().numpy(),
+                                                  torch.cat(probs).cpu().numpy(), num_classes=args.out_d)
+            logging.info(f"Test Results:\n  Test Loss: {tl:.4f}\n  Test Accuracy: {acc:.4f}")
+            save_metrics(metrics_file, args.epochs, "Test", tl, acc, bal, f1, auc, flag=1)
+    if args.dp:
+        torch.distributed.destroy_process_group()
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(description='Benchmark Vision Transformer on CIFAR-100')
+    # the reference's flags, verbatim (train.py:87-97)
+    p.add_argument('--epochs', type=int, default=20, help='number of epochs to train')
+    p.add_argument('--batch-size', type=int, default=128, help='batch size for training')
+    p.add_argument('--learning-rate', type=float, default=0.001, help='learning rate for optimizer')
+    p.add_argument('--device', type=str, default='cuda' if torch.cuda.is_available() else 'cpu',
+                   help='device to use for training (cuda/cpu)')
+    p.add_argument('--model-type', type=str, default='vanilla', help='variant to run')
+    p.add_argument('--n-blocks', type=int, default=8, help='number of transformer blocks')
+    p.add_argument('--d-hidden', type=int, default=64, help='hidden dimension of transformer block')
+    p.add_argument('--n-heads', type=int, default=8, help='number of attention heads')
+    p.add_argument('--log-dir', type=str, default='logs', help='directory to store logs')
+    # additions (defaults reproduce the geometry hard-coded at train.py:19)
+    p.add_argument('--synthetic', action='store_true', help='synthetic image stream instead of CIFAR-100')
+    p.add_argument('--steps-per-epoch', type=int, default=100, help='steps per epoch of the synthetic stream')
+    p.add_argument('--image-size', type=int, default=32)
+    p.add_argument('--in-chans', type=int, default=3)
+    p.add_argument('--n-patches', type=int, default=4)
+    p.add_argument('--out-d', type=int, default=100)
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--dp', action='store_true', help='data parallel: one process per GPU (launch with torch.distributed.run)')
+    p.add_argument('--no-step-metrics', action='store_true', help='skip per-step metric accumulation')
+    return p.parse_args(argv)
+
+
+if __name__ == "__main__":
+    main(parse())
