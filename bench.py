@@ -46,10 +46,23 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Pea
 PEAK_HBM_GBS = 8000.0
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask, cgroup quota, and the GPU box's per-GPU
+    share (16).  os.cpu_count() reports all 256 host threads and oversubscribes torch ~16x."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return int(os.environ.get("KANVIT_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(model, wl, target_s=15.0):
     """Reference-faithful CPU train step (oracle/kan_oracle.py, the checker -- never the product)."""
     from oracle import kan_oracle as ko
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     n_patches, heads, t = wl["n_patches"], wl["heads"], wl["type"]
 
@@ -146,7 +159,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = 1e3 * dt / args.steps

@@ -20,16 +20,19 @@
 #include "kan_basis.h"
 #include "kanvit_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
-constexpr int BM = 128;          // rows per block in fwd / bwd_input (4 waves x 32 rows)
-constexpr int NTHR = 256;
+constexpr int BM = 128;          // rows per block in fwd / bwd_input (4 consumer waves x 32 rows)
+constexpr int NTHR = 512;        // 4 consumer (MFMA) waves + 4 producer (load / basis) waves
+constexpr int NPROD = 256;       // producer threads
 constexpr int AS = BM + 1;       // row stride of the K-major LDS tiles
 constexpr int BIN_NC = 32;       // dY columns staged per step in bwd_input
 constexpr int BW_ROWS = 32;      // rows staged per step in bwd_weight
 constexpr int BW_AS = BW_ROWS + 1;
 constexpr int BW_NT = 2;         // 64 output columns per bwd_weight block
-constexpr int BW_TPW = 5;        // max 32x32 MFMA tiles per wave in bwd_weight
+constexpr int BW_TPW = 5;        // max 32x32 MFMA tiles per consumer wave in bwd_weight
 constexpr int BW_KC_MAX = 288;   // (BW_TPW*4 tiles / BW_NT) * 32 = 320 >= 288
 constexpr int N_CU = 256;
 
@@ -48,6 +51,7 @@ struct LayerArgs {
     long long M, ldx, ldu, ldy, bp_stride, rows_per_split;
     int I, O, groups, xmod, G, GP, order, nk, has_base, K, IC, msplit, nchunks_n;
     float rbf_inv_h;
+    int dbg;   // KANVIT_DBG ablation mask (timing experiments only; results are wrong when non-zero)
 };
 
 __device__ __forceinline__ BasisArgs make_basis(const LayerArgs& a, int g) {
@@ -62,105 +66,277 @@ __device__ __forceinline__ BasisArgs make_basis(const LayerArgs& a, int g) {
     return b;
 }
 
+__device__ __forceinline__ int kv_pow2_ge(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Producer helpers.  All global loads of a pass are issued before the first LDS store so that
+// their latencies overlap (the compiler keeps the order of the two unrolled loops).
+// ---------------------------------------------------------------------------------------------
+// rows x IC tile of a row-major matrix -> dst[r*ICP + il]; thread map (il = pt % ICR, r = pt / ICR)
+// with ICR = pow2 >= IC keeps the global reads coalesced along the feature axis without a division.
+template <int ROWS>
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, long long ld,
+                                           long long row0, long long row_end, int i0, int I, int IC, int ICP, int pt) {
+    const int ICR = kv_pow2_ge(IC);
+    const int il = pt & (ICR - 1);
+    const int rstep = NPROD / ICR;            // ICR <= 128 guaranteed by the host (IC <= 96)
+    const int r0 = pt / ICR;                  // ICR is a power of two: a shift
+    const bool col_ok = (il < IC) && (i0 + il < I);
+    for (int rb = 0; rb < ROWS; rb += 4 * rstep) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = rb + q * rstep + r0;
+            const long long m = row0 + r;
+            v[q] = (col_ok && r < ROWS && m < row_end) ? src[m * ld + i0 + il] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = rb + q * rstep + r0;
+            if (il < IC && r < ROWS) dst[r * ICP + il] = v[q];
+        }
+    }
+}
+
 // =============================================================================================
-// forward
-// grid (ceil(M/BM), ceil(O/BN), groups), 256 threads
+// forward.  grid (nsets * ceil(O/BN), ceil(M/BM)), 512 threads; nsets = groups / NSH.
+// NSH = number of groups that share ONE generated basis tile: for families without per-layer
+// basis parameters (LINEAR, CHEBY, FOURIER) the q, k and v mappings of a head read the same x
+// columns and therefore the same Phi(x), so one block evaluates Phi once and contracts it against
+// the three weight sets (NSH = 3); otherwise NSH = 1.
+// Measured on MI355X (tools/coissue_probe*.hip): the fp32-input MFMA does NOT overlap with VALU
+// work of either wave on its SIMD (time adds), unlike the bf16 MFMA.  The producer code below is
+// therefore written for minimum instruction count: per-thread pointers are set up once, bounds
+// checks collapse to wave-uniform flags on interior tiles, and all loads of a pass are issued
+// before the first LDS store.
+// Pipeline (one __syncthreads per feature chunk c):
+//   consumers: MFMA on A_s/W_s[c&1]
+//   producers: W chunk c+1 -> W_s[(c+1)&1]; basis(x_s[(c+1)&1]) -> A_s[(c+1)&1]; x chunk c+2 -> x_s[c&1]
 // =============================================================================================
-template <int FAM, int NT>
+template <int FAM, int NT, int NSH, bool FAST>
 __global__ __launch_bounds__(NTHR) void kan_fwd_kernel(const LayerArgs a) {
+    // FAST (host-checked): IC is a power of two dividing I, O % BN == 0 -- every chunk and column tile is
+    // interior, so the only remaining bounds question is the last row tile (wave-uniform flag full_m).
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 32 * NT;
+    constexpr int WROW = NSH * BN;              // floats per W_s row
+    constexpr int V4 = BN / 4;                  // float4 per W row of one group (power of two)
+    constexpr int WRS = NPROD / V4;             // W rows per staging pass
+    constexpr bool RBF = (FAM == KV_RBF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int g = blockIdx.z;
+    const bool consumer = wave < 4;
+    const int pt = tid & (NPROD - 1);
+    const int ntn = (a.O + BN - 1) / BN;
+    const int gs = blockIdx.x / ntn;
+    const int n0 = (blockIdx.x - gs * ntn) * BN;
+    const int nsets = a.groups / NSH;
+    const long long m0 = (long long)blockIdx.y * BM;
     const int IC = a.IC, GP = a.GP, ICP = IC | 1;
     const int KC = IC * GP, KCP = (KC + 1) & ~1;
+    const int XS = BM * ICP, ASZ = KCP * AS, WSZ = KCP * WROW;
+    const int nch = (a.I + IC - 1) / IC;
+    const bool full_m = (m0 + BM <= a.M);
+    const bool full_n = FAST || ((n0 + BN <= a.O) && ((a.O & 3) == 0));
+    const int mrem = full_m ? BM : (int)(a.M - m0);      // valid rows of this tile
 
-    float* x_s = smem;
-    float* u_s = x_s + BM * ICP;
-    float* A_s = u_s + (FAM == KV_RBF ? BM * ICP : 0);
-    float* W_s = A_s + KCP * AS;
+    float* x_s = smem;                          // [2][XS]
+    float* u_s = x_s + 2 * XS;                  // [2][XS]  (RBF)
+    float* A_s = u_s + (RBF ? 2 * XS : 0);      // [2][ASZ]
+    float* W_s = A_s + 2 * ASZ;                 // [2][WSZ]
 
-    const BasisArgs b = make_basis(a, g);
-    const float* xg = a.x + (long long)(g % a.xmod) * a.I;
-    const float* ug = (FAM == KV_RBF && a.u) ? a.u + (long long)g * a.I : nullptr;
-    const float* wg = a.w + (long long)g * a.K * a.O;
+    const BasisArgs b = make_basis(a, gs);      // NSH > 1 only for families without basis parameters
+    const int xcol = (NSH == 1 ? gs % a.xmod : gs) * a.I;
+    const int ldx = (int)a.ldx, ldu = (RBF && a.u) ? (int)a.ldu : (int)a.ldx;
 
-    f32x16 acc[NT];
+    // ---- producer state: uniform bases + 32-bit per-thread offsets, set up once ----
+    const int ICR = FAST ? IC : kv_pow2_ge(IC);
+    const int xl = pt & (ICR - 1), xr0 = pt / ICR, xrs = NPROD / ICR;
+    const float* xbase = a.x + m0 * a.ldx + xcol;                                        // uniform
+    const float* ubase = (RBF && a.u) ? a.u + m0 * a.ldu + (long long)gs * a.I : xbase;  // uniform
+    const int xoff = xr0 * ldx + xl, uoff = xr0 * ldu + xl;
+    const int xsoff = xr0 * ICP + xl;
+    const int wk = pt / V4, wc = (pt & (V4 - 1)) * 4;
+    const int woff = wk * a.O + wc;
+    const int gr = pt & (BM - 1), gl0 = pt >> 7;              // basis: fixed row gr, features gl0, gl0+2, ...
+
+    auto stage_x = [&](int c, int buf) {
+        float* dxs = x_s + buf * XS + xsoff;
+        float* dus = u_s + buf * XS + xsoff;
+        const float* sx = xbase + c * IC;
+        const float* su = ubase + c * IC;
+        const int npass = (BM + xrs - 1) / xrs;
+        if (FAST && full_m) {
+            for (int q0 = 0; q0 < npass; q0 += 4) {
+                float v[4], w[4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = sx[xoff + (q0 + q) * xrs * ldx];
+                    if (RBF) w[q] = su[uoff + (q0 + q) * xrs * ldu];
+                }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
-
-    if (KCP != KC)
-        for (int r = tid; r < AS; r += NTHR) A_s[KC * AS + r] = 0.0f;
-
-    for (int i0 = 0; i0 < a.I; i0 += IC) {
-        // (1) x tile, coalesced along the feature axis; (2) weight chunk, coalesced along O
-        for (int idx = tid; idx < BM * IC; idx += NTHR) {
-            const int r = idx / IC, il = idx - r * IC;
-            const long long m = m0 + r;
-            const int i = i0 + il;
-            const bool ok = (m < a.M) && (i < a.I);
-            const float xv = ok ? xg[m * a.ldx + i] : 0.0f;
-            x_s[r * ICP + il] = xv;
-            if (FAM == KV_RBF) u_s[r * ICP + il] = ok ? (ug ? ug[m * a.ldu + i] : xv) : 0.0f;
+                for (int q = 0; q < 4; ++q) {
+                    dxs[(q0 + q) * xrs * ICP] = v[q];
+                    if (RBF) dus[(q0 + q) * xrs * ICP] = w[q];
+                }
+            }
+        } else {
+            const bool col_ok = (xl < IC) && (c * IC + xl < a.I);
+            for (int q0 = 0; q0 < npass; q0 += 4) {
+                float v[4], w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = xr0 + (q0 + q) * xrs;
+                    const bool ok = col_ok && (r < mrem);
+                    v[q] = ok ? sx[xoff + (q0 + q) * xrs * ldx] : 0.0f;
+                    if (RBF) w[q] = ok ? su[uoff + (q0 + q) * xrs * ldu] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = xr0 + (q0 + q) * xrs;
+                    if (xl < IC && r < BM) {
+                        dxs[(q0 + q) * xrs * ICP] = v[q];
+                        if (RBF) dus[(q0 + q) * xrs * ICP] = w[q];
+                    }
+                }
+            }
         }
-        for (int idx = tid; idx < KCP * BN; idx += NTHR) {
-            const int kk = idx / BN, n = idx - kk * BN;
-            const int kg = i0 * GP + kk;
-            const bool ok = (kk < KC) && (kg < a.K) && (n0 + n < a.O);
-            W_s[idx] = ok ? wg[(long long)kg * a.O + n0 + n] : 0.0f;
+    };
+    auto stage_w = [&](int c, int buf) {
+        float* dst = W_s + buf * WSZ + wk * WROW + wc;
+        const int k0 = c * KC;
+        const int npass = (KCP + WRS - 1) / WRS;
+#pragma unroll
+        for (int p = 0; p < NSH; ++p) {
+            const int g = (NSH == 1) ? gs : p * nsets + gs;
+            const float* src = a.w + ((long long)g * a.K + k0) * a.O + n0;               // uniform
+            for (int q0 = 0; q0 < npass; q0 += 4) {
+                f32x4 val[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = wk + (q0 + q) * WRS;
+                    f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (kk < KC && (FAST || k0 + kk < a.K)) {
+                        const float* sp = src + woff + (q0 + q) * WRS * a.O;
+                        if (full_n) {
+                            t = *reinterpret_cast<const f32x4*>(sp);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n0 + wc + e < a.O) t[e] = sp[e];
+                        }
+                    }
+                    val[q] = t;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = wk + (q0 + q) * WRS;
+                    if (kk < KCP) *reinterpret_cast<f32x4*>(dst + (q0 + q) * WRS * WROW + p * BN) = val[q];
+                }
+            }
         }
-        __syncthreads();
-        // (3) basis values -> A_s (lane = row)
-        for (int idx = tid; idx < BM * IC; idx += NTHR) {
-            const int il = idx / BM, r = idx - il * BM;
-            const int i = i0 + il;
-            float* dst = A_s + (il * GP) * AS + r;
-            if (i < a.I) {
-                basis_fwd<FAM>(b, x_s[r * ICP + il], FAM == KV_RBF ? u_s[r * ICP + il] : 0.0f, i, dst, AS);
+    };
+    auto gen_a = [&](int c, int buf) {
+        const float* xs = x_s + buf * XS + gr * ICP;
+        const float* us = u_s + buf * XS + gr * ICP;
+        float* As = A_s + buf * ASZ + gr;
+        for (int il = gl0; il < IC; il += 2) {
+            const int i = c * IC + il;
+            float* dst = As + (il * GP) * AS;
+            if (FAST || i < a.I) {
+                basis_fwd<FAM>(b, xs[il], RBF ? us[il] : 0.0f, i, dst, AS);
             } else {
                 for (int j = 0; j < GP; ++j) dst[j * AS] = 0.0f;
             }
         }
-        __syncthreads();
-        // (4) contraction: A[row = l31][k = hf] from A_s, B[k = hf][col = l31] from W_s
-        const float* ap = A_s + hf * AS + wave * 32 + l31;
-        const float* wp = W_s + hf * BN + l31;
-        for (int s = 0; s < KCP / 2; ++s) {
-            const float av = ap[(2 * s) * AS];
+    };
+
+    f32x16 acc[NSH * NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float bv = wp[(2 * s) * BN + nt * 32];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nt], 0, 0, 0);
+    for (int t = 0; t < NSH * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // prologue: x chunk 0; then operands of chunk 0 and x chunk 1
+    if (!consumer) {
+        stage_x(0, 0);
+        if (KCP != KC)
+            for (int r = pt; r < 2 * AS; r += NPROD) A_s[(r / AS) * ASZ + KC * AS + (r % AS)] = 0.0f;
+    }
+    __syncthreads();
+    if (!consumer) {
+        stage_w(0, 0);
+        gen_a(0, 0);
+        if (nch > 1) stage_x(1, 1);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nch; ++c) {
+        if (consumer && !(a.dbg & 8)) {
+            // A[row = l31][k = hf] from A_s (lane = row), B[k = hf][col = l31] from W_s (lane = column)
+            const float* ap = A_s + (c & 1) * ASZ + hf * AS + wave * 32 + l31;
+            const float* wp = W_s + (c & 1) * WSZ + hf * WROW + l31;
+#pragma unroll 2
+            for (int s = 0; s < KCP / 2; ++s) {
+                const float av = ap[(2 * s) * AS];
+#pragma unroll
+                for (int t = 0; t < NSH * NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wp[(2 * s) * WROW + t * 32], acc[t], 0, 0, 0);
             }
+        } else if (!consumer && c + 1 < nch) {
+            if (!(a.dbg & 1)) stage_w(c + 1, (c + 1) & 1);
+            if (!(a.dbg & 2)) gen_a(c + 1, (c + 1) & 1);
+            if (c + 2 < nch && !(a.dbg & 4)) stage_x(c + 2, c & 1);
         }
         __syncthreads();
     }
 
-    float* yg = a.y + (long long)g * a.O;
-    const float* bg = a.bias ? a.bias + (long long)g * a.O : nullptr;
+    if (consumer) {
+        const int ldy = (int)a.ldy;
+        const int rbase = wave * 32 + 4 * hf;                 // kv_acc_row(r, hf) = (r&3) + 8*(r>>2) + 4*hf
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + nt * 32 + l31;
-        if (col < a.O) {
-            const float bv = bg ? bg[col] : 0.0f;
+        for (int p = 0; p < NSH; ++p) {
+            const int g = (NSH == 1) ? gs : p * nsets + gs;
+            float* yt = a.y + m0 * a.ldy + (long long)g * a.O + n0;                      // uniform
+            const float* bg = a.bias ? a.bias + (long long)g * a.O + n0 : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wave * 32 + kv_acc_row(r, hf);
-                if (m < a.M) yg[m * a.ldy + col] = acc[nt][r] + bv;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cl = nt * 32 + l31;
+                if (FAST || n0 + cl < a.O) {
+                    const float bv = bg ? bg[cl] : 0.0f;
+                    const int yo = rbase * ldy + cl;
+                    if (full_m) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            yt[yo + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[p * NT + nt][r] + bv;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (rbase + (r & 3) + 8 * (r >> 2) < mrem)
+                                yt[yo + ((r & 3) + 8 * (r >> 2)) * ldy] = acc[p * NT + nt][r] + bv;
+                    }
+                }
             }
         }
     }
 }
 
 // =============================================================================================
-// backward w.r.t. the input.  grid (ceil(M/BM), xmod); each block walks the `nshare` groups
-// that read the same x columns (q, k and v of one head) and sums their contributions in LDS.
+// backward w.r.t. the input.  grid (xmod, ceil(M/BM)), 512 threads.
+// Steps t = (feature chunk ci, sharing group p, dY column chunk cn), cn fastest.  Per step the
+// consumers contract dY[:, cn] with W^T into dPhi accumulators; when a contraction ends they park
+// the tile in dA_s (between two barriers).  SHARED (families without basis parameters): the
+// nshare groups that read the same x columns also share phi', so their dPhi tiles are summed in
+// the accumulators (one contraction over (p, n) per feature chunk) and the chain rule runs once.
+// Producers run one step ahead on the operands and one step behind on the chain rule:
+//   iteration t: operands of step t+1 -> ops[(t+1)&1]; x chunk ci at its first step;
+//                basis_bwd of the tile parked at the end of iteration t-1;
+//                du / dx write-out one iteration after the basis_bwd that produced them.
 // =============================================================================================
-template <int FAM, int KT>
+template <int FAM, int KT, bool SHARED>
 __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KCT = 32 * KT;
@@ -168,231 +344,388 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
     constexpr bool RBF = (FAM == KV_RBF);
     constexpr bool SINE = (FAM == KV_SINE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int gx = blockIdx.y;
+    const bool consumer = wave < 4;
+    const int pt = tid & (NPROD - 1);
+    const int pw = wave & 3;
+    const int gx = blockIdx.x;
+    const long long m0 = (long long)blockIdx.y * BM;
     const int nshare = a.groups / a.xmod;
     const int IC = a.IC, GP = a.GP, ICP = IC | 1;
     const int KC = IC * GP;
+    const int XS = BM * ICP;
+    const int nci = (a.I + IC - 1) / IC;
+    const int ncn = (a.O + BIN_NC - 1) / BIN_NC;
+    const int spc = nshare * ncn;                   // steps per feature chunk
+    const int T = nci * spc;
+    const bool full_m = (m0 + BM <= a.M);
+    const int mrem = full_m ? BM : (int)(a.M - m0);
+    const bool vec_n = ((a.O & 3) == 0) && (a.O % BIN_NC == 0) && ((a.ldy & 3) == 0);   // float4 operand loads
+    constexpr int OPS = BIN_NC * AS + BIN_NC * WS;  // one operand buffer: dY_s then Wt_s
 
-    float* x_s = smem;
-    float* dx_s = x_s + BM * ICP;
-    float* u_s = dx_s + BM * ICP;
-    float* du_s = u_s + (RBF ? BM * ICP : 0);
-    float* dfq_s = du_s + (RBF ? BM * ICP : 0);                 // SINE: [nshare][4 waves][G]
-    float* un = dfq_s + (SINE ? nshare * 4 * a.G : 0);
-    float* dA_s = un;                                           // [KCT][AS]   (after the MFMA loop)
-    float* dY_s = un;                                           // [BIN_NC][AS] (during the MFMA loop)
-    float* Wt_s = un + BIN_NC * AS;                             // [BIN_NC][WS]
+    float* x_s = smem;                              // [2][XS]  by ci parity
+    float* dx_s = x_s + 2 * XS;                     // [2][XS]
+    float* u_s = dx_s + 2 * XS;                     // [2][XS]  by (ci*nshare+p) parity  (RBF)
+    float* du_s = u_s + (RBF ? 2 * XS : 0);         // [2][XS]                            (RBF)
+    float* dfq_s = du_s + (RBF ? 2 * XS : 0);       // [nshare][4][G]                     (SINE)
+    float* dA_s = dfq_s + (SINE ? nshare * 4 * a.G : 0);   // [KCT][AS]
+    float* ops = dA_s + KCT * AS;                   // [2][OPS]
 
     const float* xg = a.x + (long long)gx * a.I;
     float* dxg = a.dx + (long long)gx * a.I;
+    const int ldy = (int)a.ldy;
+    const float* dyb = a.dy + m0 * a.ldy;           // uniform: this tile's dY rows
 
-    if (SINE)
-        for (int j = tid; j < nshare * 4 * a.G; j += NTHR) dfq_s[j] = 0.0f;
-
-    for (int i0 = 0; i0 < a.I; i0 += IC) {
-        for (int idx = tid; idx < BM * IC; idx += NTHR) {
-            const int r = idx / IC, il = idx - r * IC;
-            const long long m = m0 + r;
-            const int i = i0 + il;
-            x_s[r * ICP + il] = ((m < a.M) && (i < a.I)) ? xg[m * a.ldx + i] : 0.0f;
-            dx_s[r * ICP + il] = 0.0f;
-        }
-        for (int p = 0; p < nshare; ++p) {
-            const int g = p * a.xmod + gx;
-            const BasisArgs b = make_basis(a, g);
-            const float* wg = a.w + (long long)g * a.K * a.O;
-            const float* dyg = a.dy + (long long)g * a.O;
-            f32x16 acc[KT];
+    // ---- producer tasks ----
+    auto stage_ops = [&](int t) {
+        const int ci = t / spc, rem = t - ci * spc, p = rem / ncn, cn = rem - p * ncn;
+        const int g = p * a.xmod + gx, n0 = cn * BIN_NC, k0 = ci * KC;
+        float* dY_s = ops + (t & 1) * OPS;
+        float* Wt_s = dY_s + BIN_NC * AS;
+        const float* dyt = dyb + (long long)g * a.O + n0;                       // uniform
+        const float* wt = a.w + ((long long)g * a.K + k0) * a.O + n0;           // uniform
+        if (vec_n) {
+            // dY tile [BM x 32]: thread (row r = pt >> 3 (+32 per pass), 4 columns c4 = (pt & 7) * 4)
+            const int c4 = (pt & 7) * 4, r0 = pt >> 3;
+            f32x4 v[4];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
-
-            for (int n0 = 0; n0 < a.O; n0 += BIN_NC) {
-                // dY tile transposed to [n][row]; W chunk transposed to [n][k]
-                for (int idx = tid; idx < BM * BIN_NC; idx += NTHR) {
-                    const int r = idx / BIN_NC, n = idx - r * BIN_NC;
-                    const long long m = m0 + r;
-                    const bool ok = (m < a.M) && (n0 + n < a.O);
-                    dY_s[n * AS + r] = ok ? dyg[m * a.ldy + n0 + n] : 0.0f;
-                }
-                for (int idx = tid; idx < KCT * BIN_NC; idx += NTHR) {
-                    const int kk = idx / BIN_NC, n = idx - kk * BIN_NC;
-                    const int kg = i0 * GP + kk;
-                    const bool ok = (kk < KC) && (kg < a.K) && (n0 + n < a.O);
-                    Wt_s[n * WS + kk] = ok ? wg[(long long)kg * a.O + n0 + n] : 0.0f;
-                }
-                __syncthreads();
-                const float* ap = dY_s + hf * AS + wave * 32 + l31;
-                const float* wp = Wt_s + hf * WS + l31;
-#pragma unroll 4
-                for (int s = 0; s < BIN_NC / 2; ++s) {
-                    const float av = ap[(2 * s) * AS];
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) {
-                        const float bv = wp[(2 * s) * WS + kt * 32];
-                        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kt], 0, 0, 0);
-                    }
-                }
-                __syncthreads();
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + q * 32;
+                f32x4 tv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (full_m || r < mrem) tv = *reinterpret_cast<const f32x4*>(dyt + r * ldy + c4);
+                v[q] = tv;
             }
-            // accumulators -> dA_s[k][row] (lane = k: stride AS, conflict free)
+            // W chunk [KC x 32] -> Wt_s[n][kk]: rows kk = r0 + q*32 < KCT
+            f32x4 wv[KT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+            for (int q = 0; q < KT; ++q) {
+                const int kk = r0 + q * 32;
+                f32x4 tv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (kk < KC && k0 + kk < a.K) tv = *reinterpret_cast<const f32x4*>(wt + kk * a.O + c4);
+                wv[q] = tv;
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dA_s[(kt * 32 + l31) * AS + wave * 32 + kv_acc_row(r, hf)] = acc[kt][r];
-            if (RBF) {
-                const float* ug = a.u ? a.u + (long long)g * a.I : nullptr;
-                for (int idx = tid; idx < BM * IC; idx += NTHR) {
-                    const int r = idx / IC, il = idx - r * IC;
-                    const long long m = m0 + r;
-                    const int i = i0 + il;
-                    const bool ok = (m < a.M) && (i < a.I);
-                    u_s[r * ICP + il] = ok ? (ug ? ug[m * a.ldu + i] : xg[m * a.ldx + i]) : 0.0f;
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dY_s[(c4 + e) * AS + r0 + q * 32] = v[q][e];
+#pragma unroll
+            for (int q = 0; q < KT; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Wt_s[(c4 + e) * WS + r0 + q * 32] = wv[q][e];
+        } else {
+            const int n = pt & 31, rr = pt >> 5;
+            const bool nok = n0 + n < a.O;
+#pragma unroll
+            for (int rb = 0; rb < BM; rb += 32) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = rb + q * 8 + rr;
+                    v[q] = (nok && r < mrem) ? dyt[r * ldy + n] : 0.0f;
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dY_s[n * AS + rb + q * 8 + rr] = v[q];
             }
-            __syncthreads();
-            // chain rule through the basis; uniform trip count so SINE can wave-reduce dfreq
-            for (int base = 0; base < BM * IC; base += NTHR) {
-                const int idx = base + tid;
-                const int il = idx / BM, r = idx - il * BM;
-                const bool valid = (idx < BM * IC) && (i0 + il < a.I);
-                const int ilc = valid ? il : 0;
-                const int rc = valid ? r : 0;
-                float dxv, duv;
-                basis_bwd<FAM>(b, x_s[rc * ICP + ilc], RBF ? u_s[rc * ICP + ilc] : 0.0f, i0 + ilc, valid,
-                               dA_s + (ilc * GP) * AS + rc, AS, dxv, duv, SINE ? dfq_s + (p * 4 + wave) * a.G : nullptr);
-                if (valid) {
-                    dx_s[r * ICP + il] += dxv;
-                    if (RBF) du_s[r * ICP + il] = duv;
+#pragma unroll
+            for (int kb = 0; kb < KCT; kb += 32) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = kb + q * 8 + rr;
+                    v[q] = (nok && kk < KC && k0 + kk < a.K) ? wt[kk * a.O + n] : 0.0f;
                 }
-            }
-            __syncthreads();
-            if (RBF && a.du) {
-                float* dug = a.du + (long long)g * a.I;
-                for (int idx = tid; idx < BM * IC; idx += NTHR) {
-                    const int r = idx / IC, il = idx - r * IC;
-                    const long long m = m0 + r;
-                    const int i = i0 + il;
-                    if ((m < a.M) && (i < a.I)) dug[m * a.ldu + i] = du_s[r * ICP + il];
-                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Wt_s[n * WS + kb + q * 8 + rr] = v[q];
             }
         }
-        // same idx -> element map as the zeroing loop above: no barrier needed before the next chunk
-        for (int idx = tid; idx < BM * IC; idx += NTHR) {
-            const int r = idx / IC, il = idx - r * IC;
-            const long long m = m0 + r;
-            const int i = i0 + il;
-            if ((m < a.M) && (i < a.I)) dxg[m * a.ldx + i] = dx_s[r * ICP + il];
+    };
+    auto chain_rule = [&](int ci, int p) {          // dA_s holds the (ci, p) tile (SHARED: summed over p)
+        const int g = p * a.xmod + gx;
+        const int q = ci * nshare + p;
+        const BasisArgs b = make_basis(a, g);
+        const float* xs = x_s + (ci & 1) * XS;
+        float* dxs = dx_s + (ci & 1) * XS;
+        const float* us = u_s + (q & 1) * XS;
+        float* dus = du_s + (q & 1) * XS;
+        const int r = pt & (BM - 1);
+        for (int il = pt >> 7; il < ((IC + 1) & ~1); il += 2) {   // uniform trip count (SINE wave-reduces)
+            const bool valid = (il < IC) && (ci * IC + il < a.I);
+            const int ilc = valid ? il : 0;
+            float dxv, duv;
+            basis_bwd<FAM>(b, xs[r * ICP + ilc], RBF ? us[r * ICP + ilc] : 0.0f, ci * IC + ilc, valid,
+                           dA_s + (ilc * GP) * AS + r, AS, dxv, duv, SINE ? dfq_s + (p * 4 + pw) * a.G : nullptr);
+            if (valid) {
+                dxs[r * ICP + il] += dxv;
+                if (RBF) dus[r * ICP + il] = duv;
+            }
         }
+    };
+    // write a [BM x IC] LDS tile back to global (coalesced along the feature axis), optionally zeroing it
+    const int ICR = kv_pow2_ge(IC);
+    const int wl = pt & (ICR - 1), wr0 = pt / ICR, wrs = NPROD / ICR;
+    auto write_rows = [&](float* __restrict__ src, float* __restrict__ dstg, int ld, int i0, bool zero) {
+        if (wl < IC && i0 + wl < a.I) {
+            float* dt = dstg + m0 * ld + i0 + wl;
+            for (int r = wr0; r < BM; r += wrs) {
+                if (r < mrem) dt[r * ld] = src[r * ICP + wl];
+                if (zero) src[r * ICP + wl] = 0.0f;
+            }
+        } else if (zero && wl < IC) {
+            for (int r = wr0; r < BM; r += wrs) src[r * ICP + wl] = 0.0f;
+        }
+    };
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
+
+    if (!consumer) {
+        for (int j = pt; j < 2 * XS; j += NPROD) dx_s[j] = 0.0f;
+        if (SINE)
+            for (int j = pt; j < nshare * 4 * a.G; j += NPROD) dfq_s[j] = 0.0f;
+        stage_ops(0);
     }
-    if (SINE) {
+    __syncthreads();
+
+    for (int t = 0; t < T + 2; ++t) {
+        const int ci = t / spc, rem = t - ci * spc, p = rem / ncn, cn = rem - p * ncn;
+        // step t completes a contraction: per (ci, p), or per ci when the groups share the basis
+        const bool ends = (t < T) && (SHARED ? (rem == spc - 1) : (cn == ncn - 1));
+        if (consumer) {
+            if (t < T) {
+                const float* ap = ops + (t & 1) * OPS + hf * AS + wave * 32 + l31;
+                const float* wp = ops + (t & 1) * OPS + BIN_NC * AS + hf * WS + l31;
+#pragma unroll 4
+                for (int s2 = 0; s2 < BIN_NC / 2; ++s2) {
+                    const float av = ap[(2 * s2) * AS];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wp[(2 * s2) * WS + kt * 32], acc[kt], 0, 0, 0);
+                }
+            }
+        } else {
+            if (t + 1 < T) stage_ops(t + 1);
+            if (t < T && rem == 0) {                              // first step of chunk ci: its x tile
+                stage_rows<BM>(x_s + (ci & 1) * XS, xg, a.ldx, m0, a.M, ci * IC, a.I, IC, ICP, pt);
+            }
+            if (RBF && t < T && cn == 0) {                        // first step of (ci, p): its u tile
+                const int g = p * a.xmod + gx;
+                const float* ug = a.u ? a.u + (long long)g * a.I : xg;
+                stage_rows<BM>(u_s + ((ci * nshare + p) & 1) * XS, ug, a.u ? a.ldu : a.ldx, m0, a.M, ci * IC, a.I, IC, ICP, pt);
+            }
+            // (t-2): write-outs of what the chain rule of iteration t-1 produced
+            if (t >= 2) {
+                const int t2 = t - 2;
+                const int ci2 = t2 / spc, rem2 = t2 - ci2 * spc, p2 = rem2 / ncn, cn2 = rem2 - p2 * ncn;
+                const bool ended2 = SHARED ? (rem2 == spc - 1) : (cn2 == ncn - 1);
+                if (ended2) {
+                    if (RBF && a.du)
+                        write_rows(du_s + ((ci2 * nshare + p2) & 1) * XS, a.du + (long long)(p2 * a.xmod + gx) * a.I, (int)a.ldu,
+                                   ci2 * IC, false);
+                    if (p2 == nshare - 1) write_rows(dx_s + (ci2 & 1) * XS, dxg, (int)a.ldx, ci2 * IC, true);
+                }
+            }
+            // (t-1): chain rule on the tile parked at the end of iteration t-1
+            if (t >= 1 && t - 1 < T) {
+                const int t1 = t - 1;
+                const int ci1 = t1 / spc, rem1 = t1 - ci1 * spc, p1 = rem1 / ncn, cn1 = rem1 - p1 * ncn;
+                const bool ended1 = SHARED ? (rem1 == spc - 1) : (cn1 == ncn - 1);
+                if (ended1) chain_rule(ci1, p1);
+            }
+        }
+        if (ends) {
+            __syncthreads();                                      // producers are done reading dA_s
+            if (consumer) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        dA_s[(kt * 32 + l31) * AS + wave * 32 + kv_acc_row(r, hf)] = acc[kt][r];
+                        acc[kt][r] = 0.0f;
+                    }
+            }
+        }
         __syncthreads();
-        for (int j = tid; j < nshare * a.G; j += NTHR) {
+    }
+
+    if (SINE && !consumer) {
+        // every producer wave added into its own slots; combine the 4 waves in a fixed order
+        for (int j = pt; j < nshare * a.G; j += NPROD) {
             const int p = j / a.G, gg = j - p * a.G;
             const float* src = dfq_s + (p * 4) * a.G + gg;
             const float v = ((src[0] + src[a.G]) + src[2 * a.G]) + src[3 * a.G];
-            a.dparam[((long long)blockIdx.x * a.groups + (p * a.xmod + gx)) * a.G + gg] = v;
+            a.dparam[((long long)blockIdx.y * a.groups + (p * a.xmod + gx)) * a.G + gg] = v;
         }
     }
 }
 
 // =============================================================================================
-// backward w.r.t. the packed weights.  grid (feature chunks, msplit, groups * nchunks_n)
+// backward w.r.t. the packed weights.  grid (feature chunks, msplit, nsets * nchunks_n), 512 thr.
+// Steps = 32-row slices of this block's row range; producers prepare slice s+1 (dY tile, basis
+// tile) and slice s+2's x tile while the consumers contract slice s.  NSH > 1: the groups that
+// share the basis tile (q, k, v of a head for LINEAR / CHEBY / FOURIER) are contracted against ONE
+// generated tile (dY tile is [32 x NSH*64]).
 // =============================================================================================
-template <int FAM>
+template <int FAM, int NSH>
 __global__ __launch_bounds__(NTHR) void kan_bwd_weight_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 32 * BW_NT;
+    constexpr int YROW = NSH * BN;                  // floats per dY_s row
+    constexpr int TPW = (NSH == 1) ? BW_TPW : 8;    // max tiles per consumer wave
     constexpr bool RBF = (FAM == KV_RBF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const bool consumer = wave < 4;
+    const int pt = tid & (NPROD - 1);
     const int IC = a.IC, GP = a.GP, ICP = IC | 1;
     const int i0 = blockIdx.x * IC;
     const int ms = blockIdx.y;
-    const int g = blockIdx.z / a.nchunks_n;
-    const int n0 = (blockIdx.z - g * a.nchunks_n) * BN;
+    const int gs = blockIdx.z / a.nchunks_n;
+    const int n0 = (blockIdx.z - gs * a.nchunks_n) * BN;
+    const int nsets = a.groups / NSH;
     const int KC = IC * GP;
     const int KT = (KC + 31) / 32;
-    const int ntiles = KT * BW_NT;
+    const int ntiles = KT * BW_NT * NSH;
+    const int XS = BW_ROWS * ICP, YS = BW_ROWS * YROW, ASZ = KT * 32 * BW_AS;
 
-    float* x_s = smem;
-    float* u_s = x_s + BW_ROWS * ICP;
-    float* dY_s = u_s + (RBF ? BW_ROWS * ICP : 0);
-    float* A_s = dY_s + BW_ROWS * BN;              // [KT*32][BW_AS]
+    float* x_s = smem;                              // [2][XS]
+    float* u_s = x_s + 2 * XS;                      // [2][XS] (RBF)
+    float* dY_s = u_s + (RBF ? 2 * XS : 0);         // [2][YS]
+    float* A_s = dY_s + 2 * YS;                     // [2][ASZ]
 
-    const BasisArgs b = make_basis(a, g);
-    const float* xg = a.x + (long long)(g % a.xmod) * a.I;
-    const float* ug = (RBF && a.u) ? a.u + (long long)g * a.I : nullptr;
-    const float* dyg = a.dy + (long long)g * a.O;
-
-    f32x16 acc[BW_TPW];
-#pragma unroll
-    for (int j = 0; j < BW_TPW; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-
-    for (int idx = KC * BW_AS + tid; idx < KT * 32 * BW_AS; idx += NTHR) A_s[idx] = 0.0f;   // pad rows
-
+    const BasisArgs b = make_basis(a, gs);
+    const int xcol = (NSH == 1 ? gs % a.xmod : gs) * a.I;
+    const float* xg = a.x + xcol;
+    const float* ug = (RBF && a.u) ? a.u + (long long)gs * a.I : xg;
+    const long long ldu = (RBF && a.u) ? a.ldu : a.ldx;
     const long long mbeg = (long long)ms * a.rows_per_split;
     const long long mend = (mbeg + a.rows_per_split < a.M) ? mbeg + a.rows_per_split : a.M;
-    for (long long mr = mbeg; mr < mend; mr += BW_ROWS) {
-        for (int idx = tid; idx < BW_ROWS * IC; idx += NTHR) {
-            const int r = idx / IC, il = idx - r * IC;
-            const long long m = mr + r;
-            const int i = i0 + il;
-            const bool ok = (m < mend) && (i < a.I);
-            const float xv = ok ? xg[m * a.ldx + i] : 0.0f;
-            x_s[r * ICP + il] = xv;
-            if (RBF) u_s[r * ICP + il] = ok ? (ug ? ug[m * a.ldu + i] : xv) : 0.0f;
+    const int nst = (mend > mbeg) ? (int)((mend - mbeg + BW_ROWS - 1) / BW_ROWS) : 0;
+    const int ldy = (int)a.ldy;
+    const bool vec_n = ((a.O & 3) == 0) && (n0 + BN <= a.O) && ((a.ldy & 3) == 0);
+
+    auto stage_x = [&](int s, int buf) {
+        stage_rows<BW_ROWS>(x_s + buf * XS, xg, a.ldx, mbeg + (long long)s * BW_ROWS, mend, i0, a.I, IC, ICP, pt);
+        if (RBF) stage_rows<BW_ROWS>(u_s + buf * XS, ug, ldu, mbeg + (long long)s * BW_ROWS, mend, i0, a.I, IC, ICP, pt);
+    };
+    auto stage_dy = [&](int s, int buf) {           // [32 x NSH*64] tile, rows past the range are zero
+        float* dst = dY_s + buf * YS;
+        const long long mr = mbeg + (long long)s * BW_ROWS;
+        const int rows = (mend - mr < BW_ROWS) ? (int)(mend - mr) : BW_ROWS;
+        const float* dyt = a.dy + mr * a.ldy + n0;                              // uniform
+        if (vec_n) {
+            const int c4 = (pt & 15) * 4, r0 = pt >> 4;                          // 16 float4 per 64-column row, 16 rows per pass
+#pragma unroll
+            for (int p = 0; p < NSH; ++p) {
+                const int g = (NSH == 1) ? gs : p * nsets + gs;
+                f32x4 v[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = r0 + q * 16;
+                    f32x4 tv = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (r < rows) tv = *reinterpret_cast<const f32x4*>(dyt + (long long)g * a.O + r * ldy + c4);
+                    v[q] = tv;
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(dst + (r0 + q * 16) * YROW + p * BN + c4) = v[q];
+            }
+        } else {
+            const int n = pt & (BN - 1), rr = pt / BN;  // 4 rows per pass
+            const bool nok = n0 + n < a.O;
+#pragma unroll
+            for (int p = 0; p < NSH; ++p) {
+                const int g = (NSH == 1) ? gs : p * nsets + gs;
+#pragma unroll
+                for (int rb = 0; rb < BW_ROWS; rb += 16) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = rb + q * 4 + rr;
+                        v[q] = (nok && r < rows) ? dyt[(long long)g * a.O + r * ldy + n] : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[(rb + q * 4 + rr) * YROW + p * BN + n] = v[q];
+                }
+            }
         }
-        for (int idx = tid; idx < BW_ROWS * BN; idx += NTHR) {
-            const int r = idx / BN, n = idx - r * BN;
-            const long long m = mr + r;
-            const bool ok = (m < mend) && (n0 + n < a.O);
-            dY_s[idx] = ok ? dyg[m * a.ldy + n0 + n] : 0.0f;      // zero rows kill the padded rows of A_s
-        }
-        __syncthreads();
-        for (int idx = tid; idx < BW_ROWS * IC; idx += NTHR) {
-            const int il = idx / BW_ROWS, r = idx - il * BW_ROWS;
+    };
+    auto gen_a = [&](int buf) {
+        const int r = pt & (BW_ROWS - 1);
+        const float* xs = x_s + buf * XS + r * ICP;
+        const float* us = u_s + buf * XS + r * ICP;
+        float* As = A_s + buf * ASZ + r;
+        for (int il = pt >> 5; il < IC; il += NPROD / BW_ROWS) {
             const int i = i0 + il;
-            float* dst = A_s + (il * GP) * BW_AS + r;
+            float* dst = As + (il * GP) * BW_AS;
             if (i < a.I) {
-                basis_fwd<FAM>(b, x_s[r * ICP + il], RBF ? u_s[r * ICP + il] : 0.0f, i, dst, BW_AS);
+                basis_fwd<FAM>(b, xs[il], RBF ? us[il] : 0.0f, i, dst, BW_AS);
             } else {
                 for (int j = 0; j < GP; ++j) dst[j * BW_AS] = 0.0f;
             }
         }
-        __syncthreads();
-        // dW tile[k][o] += sum_rows A[row][k] * dY[row][o]: MFMA "row" index = k, contraction = row
+    };
+
+    f32x16 acc[TPW];
 #pragma unroll
-        for (int j = 0; j < BW_TPW; ++j) {
-            const int t = wave + 4 * j;
-            if (t < ntiles) {
-                const int kt = t / BW_NT, nt = t - kt * BW_NT;
-                const float* ap = A_s + (kt * 32 + l31) * BW_AS + hf;
-                const float* bp2 = dY_s + hf * BN + nt * 32 + l31;
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    if (!consumer) {
+        for (int bufi = 0; bufi < 2; ++bufi)
+            for (int idx = KC * BW_AS + pt; idx < ASZ; idx += NPROD) A_s[bufi * ASZ + idx] = 0.0f;   // pad rows
+        if (nst > 0) stage_x(0, 0);
+    }
+    __syncthreads();
+    if (!consumer && nst > 0) {
+        stage_dy(0, 0);
+        gen_a(0);
+        if (nst > 1) stage_x(1, 1);
+    }
+    __syncthreads();
+
+    constexpr int NTC = BW_NT * NSH;                // column tiles per k tile
+    for (int s = 0; s < nst; ++s) {
+        if (consumer) {
+            // dW tile[k][o] += sum_rows A[row][k] * dY[row][o]: MFMA row index = k, contraction = row
+            const float* Ab = A_s + (s & 1) * ASZ;
+            const float* Yb = dY_s + (s & 1) * YS;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int t = wave + 4 * j;
+                if (t < ntiles) {
+                    const int kt = t / NTC, nt = t - kt * NTC;
+                    const float* ap = Ab + (kt * 32 + l31) * BW_AS + hf;
+                    const float* bp2 = Yb + hf * YROW + nt * 32 + l31;
 #pragma unroll 4
-                for (int s = 0; s < BW_ROWS / 2; ++s)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp2[(2 * s) * BN], acc[j], 0, 0, 0);
+                    for (int k2 = 0; k2 < BW_ROWS / 2; ++k2)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * k2], bp2[(2 * k2) * YROW], acc[j], 0, 0, 0);
+                }
             }
+        } else if (s + 1 < nst) {
+            stage_dy(s + 1, (s + 1) & 1);
+            gen_a((s + 1) & 1);
+            if (s + 2 < nst) stage_x(s + 2, s & 1);
         }
         __syncthreads();
     }
 
-    float* slab = a.slab + ((long long)ms * a.groups + g) * a.K * a.O;
+    if (consumer) {
 #pragma unroll
-    for (int j = 0; j < BW_TPW; ++j) {
-        const int t = wave + 4 * j;
-        if (t < ntiles) {
-            const int kt = t / BW_NT, nt = t - kt * BW_NT;
-            const int col = n0 + nt * 32 + l31;
+        for (int j = 0; j < TPW; ++j) {
+            const int t = wave + 4 * j;
+            if (t < ntiles) {
+                const int kt = t / NTC, nt = t - kt * NTC;
+                const int p = nt / BW_NT, ntl = nt - p * BW_NT;
+                const int g = (NSH == 1) ? gs : p * nsets + gs;
+                float* slab = a.slab + ((long long)ms * a.groups + g) * a.K * a.O;
+                const int col = n0 + ntl * 32 + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = kt * 32 + kv_acc_row(r, hf);
-                const int k = i0 * GP + kk;
-                if (kk < KC && k < a.K && col < a.O) slab[(long long)k * a.O + col] = acc[j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = kt * 32 + kv_acc_row(r, hf);
+                    const int k = i0 * GP + kk;
+                    if (kk < KC && k < a.K && col < a.O) slab[(long long)k * a.O + col] = acc[j][r];
+                }
             }
         }
     }
@@ -433,6 +766,8 @@ int validate(const kanvit_layer_desc* d, const char* who) {
         return kv_fail(KANVIT_EINVAL, "%s: groups=%d must be a positive multiple of x_group_mod=%d", who, d->groups,
                        d->x_group_mod);
     if (d->groups > 65535) return kv_fail(KANVIT_EINVAL, "%s: groups=%d exceeds 65535", who, d->groups);
+    if ((d->M + BM - 1) / BM > 65535) return kv_fail(KANVIT_EINVAL, "%s: M=%lld exceeds %d rows per launch", who,
+                                                     (long long)d->M, 65535 * BM);
     if (d->I < 1 || d->O < 1 || d->M < 0) return kv_fail(KANVIT_EINVAL, "%s: bad sizes M=%lld I=%d O=%d", who,
                                                           (long long)d->M, d->I, d->O);
     if ((long long)d->I * gp > 0x7fffffffLL / 4) return kv_fail(KANVIT_EINVAL, "%s: K too large", who);
@@ -471,92 +806,141 @@ LayerArgs base_args(const kanvit_layer_desc* d) {
     a.has_base = d->has_base;
     a.K = d->I * a.GP;
     a.rbf_inv_h = d->rbf_inv_h;
+    const char* dbg = getenv("KANVIT_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
     return a;
 }
 
 int needs_bparams(int family) { return family == KANVIT_BSPLINE || family == KANVIT_RBF || family == KANVIT_SINE; }
 
 // ---- forward -----------------------------------------------------------------------------------
-template <int FAM, int NT>
+template <int FAM>
+constexpr bool kv_shared_basis() { return FAM == KV_LINEAR || FAM == KV_CHEBY || FAM == KV_FOURIER; }
+
+template <int FAM>
+size_t fwd_lds(int ic, int gp, int nt, int nsh) {
+    const int kcp = (ic * gp + 1) & ~1;
+    return sizeof(float) * 2 * ((size_t)BM * (ic | 1) * (FAM == KV_RBF ? 2 : 1) + (size_t)kcp * AS + (size_t)kcp * 32 * nt * nsh);
+}
+
+template <int FAM, int NT, int NSH, bool FAST>
 int launch_fwd(const LayerArgs& a, hipStream_t st) {
     constexpr int BN = 32 * NT;
-    const int ICP = a.IC | 1;
-    const int KC = a.IC * a.GP, KCP = (KC + 1) & ~1;
-    const size_t lds = sizeof(float) * ((size_t)BM * ICP * (FAM == KV_RBF ? 2 : 1) + (size_t)KCP * AS + (size_t)KCP * BN);
+    const size_t lds = fwd_lds<FAM>(a.IC, a.GP, NT, NSH);
     static bool attr_done = false;   // benign race: idempotent
     if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(kan_fwd_kernel<FAM, NT>, 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds(kan_fwd_kernel<FAM, NT, NSH, FAST>, 160 * 1024));
         attr_done = true;
     }
-    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.O + BN - 1) / BN), (unsigned)a.groups);
-    hipLaunchKernelGGL((kan_fwd_kernel<FAM, NT>), grid, dim3(NTHR), lds, st, a);
+    dim3 grid((unsigned)((a.groups / NSH) * ((a.O + BN - 1) / BN)), (unsigned)((a.M + BM - 1) / BM), 1);
+    hipLaunchKernelGGL((kan_fwd_kernel<FAM, NT, NSH, FAST>), grid, dim3(NTHR), lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_kernel");
     return 0;
+}
+
+template <int FAM, int NT, int NSH>
+int launch_fwd_sel(const LayerArgs& a, bool fast, hipStream_t st) {
+    return fast ? launch_fwd<FAM, NT, NSH, true>(a, st) : launch_fwd<FAM, NT, NSH, false>(a, st);
 }
 
 template <int FAM>
 int dispatch_fwd(LayerArgs& a, hipStream_t st) {
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
-    const int kcmax = nt == 4 ? 64 : 80;
-    int ic = kcmax / a.GP;
+    const int nshare = a.groups / a.xmod;
+    const bool share3 = kv_shared_basis<FAM>() && nshare == 3 && nt <= 2;
+    const int nsh = share3 ? 3 : 1;
+    // largest feature chunk whose two operand buffers fit the 160 KiB LDS (cap 80 columns)
+    int ic = 80 / a.GP;
     if (ic < 1) ic = 1;
     if (ic > a.I) ic = a.I;
-    a.IC = ic;
-    if (nt == 1) return launch_fwd<FAM, 1>(a, st);
-    if (nt == 2) return launch_fwd<FAM, 2>(a, st);
-    return launch_fwd<FAM, 4>(a, st);
+    while (ic > 1 && fwd_lds<FAM>(ic, a.GP, nt, nsh) > 160 * 1024) --ic;
+    if (fwd_lds<FAM>(ic, a.GP, nt, nsh) > 160 * 1024)
+        return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: %d generated columns per feature with O=%d does not fit the LDS", a.GP, a.O);
+    // fast path: power-of-two chunk dividing I, whole column tiles, 32-bit tile-local offsets
+    int icf = 1;
+    while (icf * 2 <= ic) icf *= 2;
+    const bool fast = (icf >= 8) && (a.I % icf == 0) && (a.O % (32 * nt) == 0) &&
+                      ((long long)BM * a.ldx < (1LL << 30)) && ((long long)BM * a.ldy < (1LL << 30)) &&
+                      ((long long)BM * a.ldu < (1LL << 30)) && ((long long)a.K * a.O < (1LL << 30)) && !getenv("KANVIT_NO_FAST");
+    a.IC = fast ? icf : ic;
+    if (share3) {
+        if constexpr (kv_shared_basis<FAM>()) {
+            if (nt == 1) return launch_fwd_sel<FAM, 1, 3>(a, fast, st);
+            return launch_fwd_sel<FAM, 2, 3>(a, fast, st);
+        }
+    }
+    if (nt == 1) return launch_fwd_sel<FAM, 1, 1>(a, fast, st);
+    if (nt == 2) return launch_fwd_sel<FAM, 2, 1>(a, fast, st);
+    return launch_fwd_sel<FAM, 4, 1>(a, fast, st);
 }
 
 // ---- backward input ------------------------------------------------------------------------------
-template <int FAM, int KT>
+template <int FAM>
+size_t bwd_input_lds(int ic, int gp, int G, int nshare) {
+    const int kct = 32 * ((ic * gp + 31) / 32);
+    return sizeof(float) * ((size_t)BM * (ic | 1) * (FAM == KV_RBF ? 8 : 4) + (FAM == KV_SINE ? (size_t)nshare * 4 * G : 0) +
+                            (size_t)kct * AS + 2 * ((size_t)BIN_NC * AS + (size_t)BIN_NC * (kct + 1)));
+}
+
+template <int FAM, int KT, bool SHARED>
 int launch_bwd_input(const LayerArgs& a, hipStream_t st) {
-    constexpr int KCT = 32 * KT;
-    const int ICP = a.IC | 1;
-    const int nshare = a.groups / a.xmod;
-    const size_t un = (size_t)KCT * AS > (size_t)BIN_NC * AS + (size_t)BIN_NC * (KCT + 1)
-                          ? (size_t)KCT * AS
-                          : (size_t)BIN_NC * AS + (size_t)BIN_NC * (KCT + 1);
-    const size_t lds = sizeof(float) * ((size_t)BM * ICP * (FAM == KV_RBF ? 4 : 2) +
-                                        (FAM == KV_SINE ? (size_t)nshare * 4 * a.G : 0) + un);
+    const size_t lds = bwd_input_lds<FAM>(a.IC, a.GP, a.G, a.groups / a.xmod);
     static bool attr_done = false;
     if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(kan_bwd_input_kernel<FAM, KT>, 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds(kan_bwd_input_kernel<FAM, KT, SHARED>, 160 * 1024));
         attr_done = true;
     }
-    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)a.xmod, 1);
-    hipLaunchKernelGGL((kan_bwd_input_kernel<FAM, KT>), grid, dim3(NTHR), lds, st, a);
+    dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
+    hipLaunchKernelGGL((kan_bwd_input_kernel<FAM, KT, SHARED>), grid, dim3(NTHR), lds, st, a);
     KV_LAUNCH_CHECK("kan_bwd_input_kernel");
     return 0;
 }
 
+template <int FAM, bool SHARED>
+int launch_bwd_input_kt(const LayerArgs& a, int kt, hipStream_t st) {
+    if (kt == 1) return launch_bwd_input<FAM, 1, SHARED>(a, st);
+    if (kt == 2) return launch_bwd_input<FAM, 2, SHARED>(a, st);
+    return launch_bwd_input<FAM, 3, SHARED>(a, st);
+}
+
 template <int FAM>
 int dispatch_bwd_input(LayerArgs& a, hipStream_t st) {
+    if ((long long)BM * a.ldx >= (1LL << 30) || (long long)BM * a.ldy >= (1LL << 30) || (long long)BM * a.ldu >= (1LL << 30) ||
+        (long long)a.K * a.O >= (1LL << 30))
+        return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: row strides / weight slab too large for 32-bit tile offsets");
     int ic = 96 / a.GP;
     if (ic < 1) ic = 1;
     if (ic > a.I) ic = a.I;
+    const int nshare = a.groups / a.xmod;
+    while (ic > 1 && bwd_input_lds<FAM>(ic, a.GP, a.G, nshare) > 160 * 1024) --ic;
+    if (bwd_input_lds<FAM>(ic, a.GP, a.G, nshare) > 160 * 1024)
+        return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: tile does not fit the LDS");
     a.IC = ic;
     const int kt = (ic * a.GP + 31) / 32;
-    if (kt == 1) return launch_bwd_input<FAM, 1>(a, st);
-    if (kt == 2) return launch_bwd_input<FAM, 2>(a, st);
-    return launch_bwd_input<FAM, 3>(a, st);
+    if (kv_shared_basis<FAM>() && nshare > 1) return launch_bwd_input_kt<FAM, true>(a, kt, st);
+    return launch_bwd_input_kt<FAM, false>(a, kt, st);
 }
 
 // ---- backward weight -----------------------------------------------------------------------------
 struct BwPlan {
-    int ic, nfchunks, nchunks_n, msplit;
+    int ic, nfchunks, nchunks_n, msplit, nsh;
     long long rows_per_split;
 };
 
 BwPlan plan_bwd_weight(const kanvit_layer_desc* d) {
     BwPlan p;
     const int gp = gp_of(d);
+    const int nshare = d->groups / d->x_group_mod;
+    const bool shared_fam = d->family == KANVIT_LINEAR || d->family == KANVIT_CHEBY || d->family == KANVIT_FOURIER;
+    p.nsh = (shared_fam && nshare == 3) ? 3 : 1;
+    // NSH = 3: 6 column tiles per k tile, at most 8 tiles per wave -> KT <= 5 (KC <= 160)
+    const int kcmax = p.nsh == 3 ? 160 : BW_KC_MAX;
     int ic = 64;
-    while (ic > 1 && ic * gp > BW_KC_MAX) ic >>= 1;
-    if (ic > d->I) ic = d->I;
+    while (ic > 1 && (ic * gp > kcmax || ic / 2 >= d->I)) ic >>= 1;
     p.ic = ic;
     p.nfchunks = (d->I + ic - 1) / ic;
     p.nchunks_n = (d->O + 32 * BW_NT - 1) / (32 * BW_NT);
-    const long long base = (long long)p.nfchunks * p.nchunks_n * d->groups;
+    const long long base = (long long)p.nfchunks * p.nchunks_n * (d->groups / p.nsh);
     long long want = (4LL * N_CU + base - 1) / base;                      // ~4 blocks per CU over the chip
     const long long maxsplit = (d->M + 4 * BW_ROWS - 1) / (4 * BW_ROWS);  // at least 128 rows per split
     if (want > maxsplit) want = maxsplit;
@@ -571,21 +955,34 @@ BwPlan plan_bwd_weight(const kanvit_layer_desc* d) {
     return p;
 }
 
-template <int FAM>
-int launch_bwd_weight(const LayerArgs& a, const BwPlan& p, hipStream_t st) {
+template <int FAM, int NSH>
+int launch_bwd_weight_n(const LayerArgs& a, const BwPlan& p, hipStream_t st) {
     const int ICP = a.IC | 1;
     const int KT = (a.IC * a.GP + 31) / 32;
-    const size_t lds = sizeof(float) * ((size_t)BW_ROWS * ICP * (FAM == KV_RBF ? 2 : 1) + (size_t)BW_ROWS * 32 * BW_NT +
-                                        (size_t)KT * 32 * BW_AS);
+    const size_t lds = sizeof(float) * 2 * ((size_t)BW_ROWS * ICP * (FAM == KV_RBF ? 2 : 1) + (size_t)BW_ROWS * 32 * BW_NT * NSH +
+                                            (size_t)KT * 32 * BW_AS);
+    if (lds > 160 * 1024) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: tile does not fit the LDS");
+    if (KT * BW_NT * NSH > 4 * ((NSH == 1) ? BW_TPW : 8))
+        return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: internal tiling error");
     static bool attr_done = false;
     if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(kan_bwd_weight_kernel<FAM>, 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds(kan_bwd_weight_kernel<FAM, NSH>, 160 * 1024));
         attr_done = true;
     }
-    dim3 grid((unsigned)p.nfchunks, (unsigned)p.msplit, (unsigned)(a.groups * p.nchunks_n));
-    hipLaunchKernelGGL((kan_bwd_weight_kernel<FAM>), grid, dim3(NTHR), lds, st, a);
+    dim3 grid((unsigned)p.nfchunks, (unsigned)p.msplit, (unsigned)((a.groups / NSH) * p.nchunks_n));
+    hipLaunchKernelGGL((kan_bwd_weight_kernel<FAM, NSH>), grid, dim3(NTHR), lds, st, a);
     KV_LAUNCH_CHECK("kan_bwd_weight_kernel");
     return 0;
+}
+
+template <int FAM>
+int launch_bwd_weight(const LayerArgs& a, const BwPlan& p, hipStream_t st) {
+    if ((long long)BW_ROWS * a.ldy >= (1LL << 30))
+        return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: ldy too large for 32-bit tile offsets");
+    if (p.nsh == 3) {
+        if constexpr (kv_shared_basis<FAM>()) return launch_bwd_weight_n<FAM, 3>(a, p, st);
+    }
+    return launch_bwd_weight_n<FAM, 1>(a, p, st);
 }
 
 #define KV_FAMILY_SWITCH(fam, CALL)                                   \
