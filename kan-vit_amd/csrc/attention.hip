@@ -38,19 +38,76 @@ struct AttnArgs {
     float* dv;
     float* delta;
     long long qsb, qsh, qsn, ksb, ksh, ksn, vsb, vsh, vsn, osb, osh, osn;
-    int B, H, N, D, causal, nkt;
+    int B, H, N, D, causal, nkt, vec;
     float scale;
 };
 
+// Fill dst[rows][KS] from src rows row0.. (row stride stride_n), zero-padding rows >= N and columns
+// >= D.  VEC path (D, strides and base 16-byte aligned): float4 global loads, four passes issued
+// before the first LDS store so their latencies overlap; scalar path for odd head sizes.
 template <int DT>
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src, long long stride_n,
-                                          int row0, int rows, int N, int D, int tid, int nthr) {
+                                          int row0, int rows, int N, int D, int tid, int nthr, bool vec) {
     constexpr int W = 32 * DT;
     constexpr int KS = W + 1;
-    for (int idx = tid; idx < rows * W; idx += nthr) {
-        const int r = idx / W, c = idx - r * W;
-        const int n = row0 + r;
-        dst[r * KS + c] = (n < N && c < D) ? src[(long long)n * stride_n + c] : 0.0f;
+    if (vec) {
+        constexpr int W4 = W / 4;                 // float4 per padded row (8 or 16)
+        const int c4 = (tid & (W4 - 1)) * 4, r0 = tid / W4, rp = nthr / W4;
+        const bool cok = c4 < D;
+        const float* sp = src + c4;
+        for (int rb = 0; rb < rows; rb += 4 * rp) {
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb + q * rp + r0;
+                const int n = row0 + r;
+                f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (cok && r < rows && n < N) t = *reinterpret_cast<const f32x4*>(sp + (long long)n * stride_n);
+                v[q] = t;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb + q * rp + r0;
+                if (r < rows) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[r * KS + c4 + e] = v[q][e];
+                }
+            }
+        }
+    } else {
+        for (int idx = tid; idx < rows * W; idx += nthr) {
+            const int r = idx / W, c = idx - r * W;
+            const int n = row0 + r;
+            dst[r * KS + c] = (n < N && c < D) ? src[(long long)n * stride_n + c] : 0.0f;
+        }
+    }
+}
+
+// One wave writes its [32][KS] staging tile to 32 consecutive global rows (float4 when aligned).
+template <int DT>
+__device__ __forceinline__ void store_tile(float* __restrict__ dstg, long long stride_n, int row0, int N, int D,
+                                           const float* __restrict__ T, int lane, bool vec) {
+    constexpr int W = 32 * DT;
+    constexpr int KS = W + 1;
+    if (vec) {
+        constexpr int W4 = W / 4;
+        const int c4 = (lane & (W4 - 1)) * 4, r0 = lane / W4, rp = 64 / W4;
+        if (c4 < D) {
+#pragma unroll 4
+            for (int r = r0; r < 32; r += rp) {
+                const int n = row0 + r;
+                if (n < N) {
+                    f32x4 v = {T[r * KS + c4], T[r * KS + c4 + 1], T[r * KS + c4 + 2], T[r * KS + c4 + 3]};
+                    *reinterpret_cast<f32x4*>(dstg + (long long)n * stride_n + c4) = v;
+                }
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 32 * D; idx += 64) {
+            const int r = idx / D, c = idx - r * D;
+            const int n = row0 + r;
+            if (n < N) dstg[(long long)n * stride_n + c] = T[r * KS + c];
+        }
     }
 }
 
@@ -73,14 +130,14 @@ __global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
     const float* vb = a.v + bi * a.vsb + hi * a.vsh;
     float* ob = a.out + bi * a.osb + hi * a.osh;
 
-    load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, ATHR);
-    load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, ATHR);
+    load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, ATHR, a.vec);
+    load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, ATHR, a.vec);
 
     const float sc2 = a.scale * LOG2E;
     const int niter = (nkt + 3) / 4;
     for (int it = 0; it < niter; ++it) {
         const int qt = it * 4 + wave;        // tiles past nkt run on zero rows and store nothing
-        load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64);
+        load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();                     // also covers the K/V fill on the first trip
 
         float qf[16 * DT];
@@ -159,11 +216,7 @@ __global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
             for (int r = 0; r < 16; ++r) Q_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = oacc[dt][r];
         __syncthreads();
         if (qt < nkt) {
-            for (int idx = lane; idx < 32 * D; idx += 64) {
-                const int r = idx / D, c = idx - r * D;
-                const int n = qt * 32 + r;
-                if (n < N) ob[(long long)n * a.osn + c] = Q_w[r * KS + c];
-            }
+            store_tile<DT>(ob, a.osn, qt * 32, N, D, Q_w, lane, a.vec && ((uintptr_t)ob % 16 == 0));
             if (hf == 0 && qrow < N && a.lse) a.lse[(long long)bh * N + qrow] = mx * a.scale + logf(sum);
         }
         __syncthreads();
@@ -219,8 +272,8 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
     float* dkb = a.dk + bi * a.ksb + hi * a.ksh;
     float* dvb = a.dv + bi * a.vsb + hi * a.vsh;
 
-    load_tile<DT>(Q_s, qb, a.qsn, 0, NP, N, D, tid, ATHR);
-    load_tile<DT>(dO_s, dob, a.osn, 0, NP, N, D, tid, ATHR);
+    load_tile<DT>(Q_s, qb, a.qsn, 0, NP, N, D, tid, ATHR, a.vec);
+    load_tile<DT>(dO_s, dob, a.osn, 0, NP, N, D, tid, ATHR, a.vec);
     for (int n = tid; n < NP; n += ATHR) {
         lse_s[n] = (n < N) ? a.lse_in[(long long)bh * N + n] * LOG2E : INFINITY;   // exp2(-inf) = 0 on pad rows
         dl_s[n] = (n < N) ? a.delta_in[(long long)bh * N + n] : 0.0f;
@@ -234,12 +287,12 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
         const bool key_ok = (jt < nkt) && (key < N);
         // K and V fragments of this wave's keys (B operands): stage through the wave's tile
         float kf[16 * DT], vf[16 * DT];
-        load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64);
+        load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
         __syncthreads();
-        load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64);
+        load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
@@ -294,24 +347,14 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dkacc[dt][r];
         __syncthreads();
-        if (jt < nkt)
-            for (int idx = lane; idx < 32 * D; idx += 64) {
-                const int r = idx / D, c = idx - r * D;
-                const int n = jt * 32 + r;
-                if (n < N) dkb[(long long)n * a.ksn + c] = T_w[r * KS + c];
-            }
+        if (jt < nkt) store_tile<DT>(dkb, a.ksn, jt * 32, N, D, T_w, lane, a.vec && ((uintptr_t)dkb % 16 == 0));
         __syncthreads();
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dvacc[dt][r];
         __syncthreads();
-        if (jt < nkt)
-            for (int idx = lane; idx < 32 * D; idx += 64) {
-                const int r = idx / D, c = idx - r * D;
-                const int n = jt * 32 + r;
-                if (n < N) dvb[(long long)n * a.vsn + c] = T_w[r * KS + c];
-            }
+        if (jt < nkt) store_tile<DT>(dvb, a.vsn, jt * 32, N, D, T_w, lane, a.vec && ((uintptr_t)dvb % 16 == 0));
         __syncthreads();
     }
 }
@@ -336,8 +379,8 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
     const float* dob = a.d_o + bi * a.osb + hi * a.osh;
     float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
 
-    load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, ATHR);
-    load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, ATHR);
+    load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, ATHR, a.vec);
+    load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, ATHR, a.vec);
     const float sc2 = a.scale * LOG2E;
 
     const int niter = (nkt + 3) / 4;
@@ -346,12 +389,12 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
         const int qrow = qt * 32 + l31;
         const bool q_ok = (qt < nkt) && (qrow < N);
         float qf[16 * DT], dof[16 * DT];
-        load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64);
+        load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
         __syncthreads();
-        load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64);
+        load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
@@ -400,12 +443,7 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dqacc[dt][r];
         __syncthreads();
-        if (qt < nkt)
-            for (int idx = lane; idx < 32 * D; idx += 64) {
-                const int r = idx / D, c = idx - r * D;
-                const int n = qt * 32 + r;
-                if (n < N) dqb[(long long)n * a.qsn + c] = T_w[r * KS + c];
-            }
+        if (qt < nkt) store_tile<DT>(dqb, a.qsn, qt * 32, N, D, T_w, lane, a.vec && ((uintptr_t)dqb % 16 == 0));
         __syncthreads();
     }
 }
@@ -432,6 +470,9 @@ AttnArgs make_args(const kanvit_attn_desc* d) {
     a.ksb = d->k_stride_b; a.ksh = d->k_stride_h; a.ksn = d->k_stride_n;
     a.vsb = d->v_stride_b; a.vsh = d->v_stride_h; a.vsn = d->v_stride_n;
     a.osb = d->o_stride_b; a.osh = d->o_stride_h; a.osn = d->o_stride_n;
+    const long long strides[] = {a.qsb, a.qsh, a.qsn, a.ksb, a.ksh, a.ksn, a.vsb, a.vsh, a.vsn, a.osb, a.osh, a.osn};
+    a.vec = (d->D % 4 == 0);
+    for (long long sd : strides) a.vec = a.vec && (sd % 4 == 0);
     return a;
 }
 
@@ -488,6 +529,7 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     if (d->B == 0) return 0;
     AttnArgs a = make_args(d);
     a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
+    a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     return d->D <= 32 ? dispatch_fwd<1>(a, st) : dispatch_fwd<2>(a, st);
 }
@@ -512,6 +554,7 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     AttnArgs a = make_args(d);
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse_in = lse; a.d_o = d_o;
     a.dq = dq; a.dk = dk; a.dv = dv; a.delta = delta_ws; a.delta_in = delta_ws;
+    a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)d->B * d->H * d->N;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
