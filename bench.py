@@ -192,6 +192,13 @@ def main():
             else:
                 out["roofline"] = {"bound": "hbm", "achieved": k["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(k["GB/s"] / PEAK_HBM_GBS, 4), "traffic": None}
+            try:      # HBM bytes per launch from the committed PMC pass, when it was taken on this very workload
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                rec = pmc["kernels"].get(dom)
+                if pmc["workload"] == args.workload and pmc["per_gpu_batch"] == wl["batch"] and rec and rec["write_kib"] is not None:
+                    out["roofline"]["traffic"] = (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024
+            except Exception:
+                pass
             out["roofline"].update({"kernel": dom, "avg_launch_ms": k["avg_ms"], "arith_intensity_flop_per_byte": round(ai, 1),
                                     "hbm_GB/s": k["GB/s"], "hbm_frac": round(k["GB/s"] / PEAK_HBM_GBS, 4)})
             out["kernels"] = kernels
