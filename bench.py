@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--bucket-mib", type=float, default=64.0)
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="capture the whole train step in a HIP graph (auto: single GPU and a launch-bound workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -118,7 +120,8 @@ def main():
     model = VisionTransformer(wl["chw"], wl["n_patches"], wl["n_blocks"], wl["d"], wl["heads"], wl["out_d"],
                               type=wl["type"]).to(dev)
     kdp.broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and wl["d"] <= 128)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
     reducer = kdp.GradReducer(model.parameters(), bucket_mib=args.bucket_mib) if world > 1 else None
     crit = torch.nn.CrossEntropyLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -145,16 +148,47 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if not args.no_kernel_timer:
-        ops.timer = ops.KernelTimer()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    kern = ops.timer.summary() if ops.timer is not None else {}
-    ops.timer = None
+    kern = {}
+    if use_graph:
+        # Launch-bound geometries (MNIST-tiny, train.py defaults): ~1 ms of kernels behind ~5-14 ms of launches.
+        # Capture forward + loss + backward + Adam once and replay it: HIP graphs instead of a tracing compiler.
+        # Per-kernel event timing cannot run inside a capture, so the roofline leg times 3 eager steps first.
+        if not args.no_kernel_timer:
+            ops.timer = ops.KernelTimer()
+            for _ in range(3):
+                step()
+            kern = ops.timer.summary()
+            for r in kern.values():
+                r["launches"] = r["launches"] * args.steps / 3.0
+                r["total_ms"] = r["total_ms"] * args.steps / 3.0
+            ops.timer = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        fence()
+        dt = time.perf_counter() - t0
+        loss = static_loss
+    else:
+        if not args.no_kernel_timer:
+            ops.timer = ops.KernelTimer()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        dt = time.perf_counter() - t0
+        kern = ops.timer.summary() if ops.timer is not None else {}
+        ops.timer = None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -171,7 +205,7 @@ def main():
             "config": {"workload": args.workload, "model_type": wl["type"], "image": list(wl["chw"]),
                        "n_patches": wl["n_patches"], "n_blocks": wl["n_blocks"], "d_hidden": wl["d"],
                        "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],
-                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3)", "loss_after": round(final_loss, 4)},
+                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3)", "hip_graph": bool(use_graph), "loss_after": round(final_loss, 4)},
         }
         kernels = {}
         for tag, r in kern.items():
