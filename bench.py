@@ -46,6 +46,22 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Pea
 PEAK_HBM_GBS = 8000.0
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the C-level stdout when the first communicator is created; the
+    contract is ONE JSON line on stdout, so fd 1 points at stderr while the process group comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def host_cores():
     """CPU cores this process may really use: affinity mask, cgroup quota, and the GPU box's per-GPU
     share (16).  os.cpu_count() reports all 256 host threads and oversubscribes torch ~16x."""
@@ -106,8 +122,12 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    force_dp = os.environ.get("KANVIT_FORCE_DP") == "1" and "RANK" in os.environ   # 1-rank rehearsal of the RCCL path
+    if world > 1 or force_dp:
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))          # forces communicator creation (and its banner) now
+            torch.cuda.synchronize()
 
     from kanvit import dp as kdp
     from kanvit import ops
@@ -120,9 +140,9 @@ def main():
     model = VisionTransformer(wl["chw"], wl["n_patches"], wl["n_blocks"], wl["d"], wl["heads"], wl["out_d"],
                               type=wl["type"]).to(dev)
     kdp.broadcast_parameters(model)
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and wl["d"] <= 128)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and not force_dp and wl["d"] <= 128)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph)
-    reducer = kdp.GradReducer(model.parameters(), bucket_mib=args.bucket_mib) if world > 1 else None
+    reducer = kdp.GradReducer(model.parameters(), bucket_mib=args.bucket_mib, always_reduce=force_dp) if (world > 1 or force_dp) else None
     crit = torch.nn.CrossEntropyLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(wl["batch"], *wl["chw"], device=dev, generator=g)
@@ -142,7 +162,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -190,7 +210,7 @@ def main():
         kern = ops.timer.summary() if ops.timer is not None else {}
         ops.timer = None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     final_loss = float(loss.detach())
@@ -240,7 +260,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, wl)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

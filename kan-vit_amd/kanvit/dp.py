@@ -20,11 +20,13 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mib: float = 64.0,
-                 group: Optional[dist.ProcessGroup] = None, overlap: bool = True):
+                 group: Optional[dist.ProcessGroup] = None, overlap: bool = True, always_reduce: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.overlap = overlap and self.world > 1
+        # always_reduce: issue the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.active = dist.is_initialized() and (self.world > 1 or always_reduce)
+        self.overlap = overlap and self.active
         self.buckets: List[torch.Tensor] = []
         self._bucket_of = {}
         self._pending: List[int] = []
@@ -72,7 +74,7 @@ class GradReducer:
 
     def finish(self):
         """Wait for (or, without overlap, perform) the all-reduces and turn sums into means."""
-        if self.world == 1:
+        if not self.active:
             return
         if not self.overlap:
             for bi in range(len(self.buckets)):

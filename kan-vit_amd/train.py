@@ -51,7 +51,7 @@ def main(args):
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         local = int(os.environ.get("LOCAL_RANK", rank))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     device = torch.device(args.device if not args.dp else f"cuda:{local}")
     if device.type != "cuda":
         raise SystemExit("this build runs the hot path on the MI355X only; --device must be a cuda device")
