@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--bucket-mib", type=float, default=64.0)
+    ap.add_argument("--amp", choices=["off", "bf16"], default="off",
+                    help="bf16 autocast for the stock dense ops (FF GEMMs); the kanvit kernels stay fp32 at their boundary")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="capture the whole train step in a HIP graph (auto: single GPU and a launch-bound workload)")
     args = ap.parse_args()
@@ -149,7 +151,8 @@ def main():
     y = torch.randint(0, wl["out_d"], (wl["batch"],), device=dev, generator=g)
 
     def step():
-        loss = crit(model(x), y)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.amp == "bf16"):
+            loss = crit(model(x), y)
         if reducer is not None:
             reducer.zero_grad()
         else:
@@ -221,7 +224,8 @@ def main():
             "metric": "images/sec (train step) KAN-ViT 224x224" if "224" in args.workload else "images/sec (train step)",
             "value": round(world * wl["batch"] * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.amp == "off" else "bf16 autocast (stock GEMMs) + f32 kanvit kernels", "data": "synthetic",
             "config": {"workload": args.workload, "model_type": wl["type"], "image": list(wl["chw"]),
                        "n_patches": wl["n_patches"], "n_blocks": wl["n_blocks"], "d_hidden": wl["d"],
                        "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],

@@ -82,22 +82,28 @@ template <int ROWS>
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, long long ld,
                                            long long row0, long long row_end, int i0, int I, int IC, int ICP, int pt) {
     const int ICR = kv_pow2_ge(IC);
+    const int lg = __builtin_ctz(ICR);
     const int il = pt & (ICR - 1);
-    const int rstep = NPROD / ICR;            // ICR <= 128 guaranteed by the host (IC <= 96)
-    const int r0 = pt / ICR;                  // ICR is a power of two: a shift
+    const int rstep = NPROD >> lg;            // ICR <= 128 guaranteed by the host (IC <= 96)
+    const int r0 = pt >> lg;
     const bool col_ok = (il < IC) && (i0 + il < I);
-    for (int rb = 0; rb < ROWS; rb += 4 * rstep) {
-        float v[4];
+    const float* base = src + row0 * ld + i0;                      // uniform
+    const int ldi = (int)ld;
+    const int nrows = (row_end - row0 < ROWS) ? (int)(row_end - row0) : ROWS;   // valid rows (may be <= 0)
+    const int off = r0 * ldi + il;
+    float* d = dst + r0 * ICP + il;
+    constexpr int NB = ROWS >= 128 ? 8 : 4;      // loads in flight per round: one memory latency per round
+    for (int rb = 0; rb < ROWS; rb += NB * rstep) {
+        float v[NB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = rb + q * rstep + r0;
-            const long long m = row0 + r;
-            v[q] = (col_ok && r < ROWS && m < row_end) ? src[m * ld + i0 + il] : 0.0f;
+        for (int q = 0; q < NB; ++q) {
+            const int r = rb + q * rstep;
+            v[q] = (col_ok && r0 + r < nrows) ? base[off + r * ldi] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = rb + q * rstep + r0;
-            if (il < IC && r < ROWS) dst[r * ICP + il] = v[q];
+        for (int q = 0; q < NB; ++q) {
+            const int r = rb + q * rstep;
+            if (il < IC && r0 + r < ROWS) d[r * ICP] = v[q];
         }
     }
 }
@@ -154,7 +160,8 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_kernel(const LayerArgs a) {
 
     // ---- producer state: uniform bases + 32-bit per-thread offsets, set up once ----
     const int ICR = FAST ? IC : kv_pow2_ge(IC);
-    const int xl = pt & (ICR - 1), xr0 = pt / ICR, xrs = NPROD / ICR;
+    const int xlg = __builtin_ctz(ICR);
+    const int xl = pt & (ICR - 1), xr0 = pt >> xlg, xrs = NPROD >> xlg;
     const float* xbase = a.x + m0 * a.ldx + xcol;                                        // uniform
     const float* ubase = (RBF && a.u) ? a.u + m0 * a.ldu + (long long)gs * a.I : xbase;  // uniform
     const int xoff = xr0 * ldx + xl, uoff = xr0 * ldu + xl;
@@ -374,10 +381,10 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
     float* dxg = a.dx + (long long)gx * a.I;
     const int ldy = (int)a.ldy;
     const float* dyb = a.dy + m0 * a.ldy;           // uniform: this tile's dY rows
+    if (a.dbg & 32) return;                         // ablation: launch + residency cost only
 
     // ---- producer tasks ----
-    auto stage_ops = [&](int t) {
-        const int ci = t / spc, rem = t - ci * spc, p = rem / ncn, cn = rem - p * ncn;
+    auto stage_ops = [&](int t, int ci, int p, int cn) {
         const int g = p * a.xmod + gx, n0 = cn * BIN_NC, k0 = ci * KC;
         float* dY_s = ops + (t & 1) * OPS;
         float* Wt_s = dY_s + BIN_NC * AS;
@@ -461,7 +468,8 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
     };
     // write a [BM x IC] LDS tile back to global (coalesced along the feature axis), optionally zeroing it
     const int ICR = kv_pow2_ge(IC);
-    const int wl = pt & (ICR - 1), wr0 = pt / ICR, wrs = NPROD / ICR;
+    const int wlg = __builtin_ctz(ICR);
+    const int wl = pt & (ICR - 1), wr0 = pt >> wlg, wrs = NPROD >> wlg;
     auto write_rows = [&](float* __restrict__ src, float* __restrict__ dstg, int ld, int i0, bool zero) {
         if (wl < IC && i0 + wl < a.I) {
             float* dt = dstg + m0 * ld + i0 + wl;
@@ -484,16 +492,24 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
         for (int j = pt; j < 2 * XS; j += NPROD) dx_s[j] = 0.0f;
         if (SINE)
             for (int j = pt; j < nshare * 4 * a.G; j += NPROD) dfq_s[j] = 0.0f;
-        stage_ops(0);
+        stage_ops(0, 0, 0, 0);
     }
     __syncthreads();
 
+    // (ci, p, cn) of steps t, t+1, t-1, t-2 are carried incrementally: runtime integer division costs ~25 scalar
+    // instructions on this ISA and the loop needed eight of them per iteration.
+    int ci = 0, p = 0, cn = 0;                 // step t
+    int ci1 = 0, p1 = 0, cn1 = 0;              // step t-1 (valid for t >= 1)
+    int ci2 = 0, p2 = 0, cn2 = 0;              // step t-2 (valid for t >= 2)
     for (int t = 0; t < T + 2; ++t) {
-        const int ci = t / spc, rem = t - ci * spc, p = rem / ncn, cn = rem - p * ncn;
+        const int rem = p * ncn + cn;
+        int cin = ci, pn = p, cnn = cn + 1;    // step t+1
+        if (cnn == ncn) { cnn = 0; ++pn; }
+        if (pn == nshare) { pn = 0; ++cin; }
         // step t completes a contraction: per (ci, p), or per ci when the groups share the basis
         const bool ends = (t < T) && (SHARED ? (rem == spc - 1) : (cn == ncn - 1));
         if (consumer) {
-            if (t < T) {
+            if (t < T && !(a.dbg & 8)) {
                 const float* ap = ops + (t & 1) * OPS + hf * AS + wave * 32 + l31;
                 const float* wp = ops + (t & 1) * OPS + BIN_NC * AS + hf * WS + l31;
 #pragma unroll 4
@@ -505,8 +521,8 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
                 }
             }
         } else {
-            if (t + 1 < T) stage_ops(t + 1);
-            if (t < T && rem == 0) {                              // first step of chunk ci: its x tile
+            if (t + 1 < T && !(a.dbg & 1)) stage_ops(t + 1, cin, pn, cnn);
+            if (t < T && rem == 0 && !(a.dbg & 16)) {             // first step of chunk ci: its x tile
                 stage_rows<BM>(x_s + (ci & 1) * XS, xg, a.ldx, m0, a.M, ci * IC, a.I, IC, ICP, pt);
             }
             if (RBF && t < T && cn == 0) {                        // first step of (ci, p): its u tile
@@ -516,10 +532,9 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
             }
             // (t-2): write-outs of what the chain rule of iteration t-1 produced
             if (t >= 2) {
-                const int t2 = t - 2;
-                const int ci2 = t2 / spc, rem2 = t2 - ci2 * spc, p2 = rem2 / ncn, cn2 = rem2 - p2 * ncn;
+                const int rem2 = p2 * ncn + cn2;
                 const bool ended2 = SHARED ? (rem2 == spc - 1) : (cn2 == ncn - 1);
-                if (ended2) {
+                if (ended2 && !(a.dbg & 16)) {
                     if (RBF && a.du)
                         write_rows(du_s + ((ci2 * nshare + p2) & 1) * XS, a.du + (long long)(p2 * a.xmod + gx) * a.I, (int)a.ldu,
                                    ci2 * IC, false);
@@ -528,15 +543,14 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
             }
             // (t-1): chain rule on the tile parked at the end of iteration t-1
             if (t >= 1 && t - 1 < T) {
-                const int t1 = t - 1;
-                const int ci1 = t1 / spc, rem1 = t1 - ci1 * spc, p1 = rem1 / ncn, cn1 = rem1 - p1 * ncn;
+                const int rem1 = p1 * ncn + cn1;
                 const bool ended1 = SHARED ? (rem1 == spc - 1) : (cn1 == ncn - 1);
-                if (ended1) chain_rule(ci1, p1);
+                if (ended1 && !(a.dbg & 2)) chain_rule(ci1, p1);
             }
         }
         if (ends) {
             __syncthreads();                                      // producers are done reading dA_s
-            if (consumer) {
+            if (consumer && !(a.dbg & 64)) {
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -547,6 +561,9 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
             }
         }
         __syncthreads();
+        ci2 = ci1; p2 = p1; cn2 = cn1;
+        ci1 = ci; p1 = p; cn1 = cn;
+        ci = cin; p = pn; cn = cnn;
     }
 
     if (SINE && !consumer) {

@@ -111,10 +111,17 @@ def _desc(cfg: LayerCfg, M: int, ldx: int, ldu: int, ldy: int, bp_stride: int) -
                      cfg.rbf_inv_h, 0, M, ldx, ldu, ldy, bp_stride)
 
 
+_fwd_f32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+# Under torch.autocast (bench.py --amp bf16: the stock FF GEMMs run on the bf16 matrix cores) the kanvit ops
+# keep computing in fp32: inputs are cast to fp32 at the boundary and autocast is off inside.
+
+
 class _KanLayerFn(torch.autograd.Function):
     """y[M, groups*O] = fused_kan(x[M, x_group_mod*I], u, w[groups, K, O], bparams, bias)."""
 
     @staticmethod
+    @_fwd_f32
     def forward(ctx, x, u, w, bparams, bias, cfg: LayerCfg):
         for n, t in (("x", x), ("u", u), ("w", w), ("bparams", bparams), ("bias", bias)):
             _require_gpu_f32(n, t)
@@ -144,7 +151,9 @@ class _KanLayerFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd
     def backward(ctx, dy):
+        dy = dy.float()
         cfg: LayerCfg = ctx.cfg
         x, u, w, bparams = ctx.saved_tensors
         dy = dy.contiguous()
@@ -234,6 +243,7 @@ class _AttnPackedFn(torch.autograd.Function):
     """qkv[B, N, 3, H, D] (the layout the grouped q|k|v KAN launch writes) -> o[B, N, H*D]."""
 
     @staticmethod
+    @_fwd_f32
     def forward(ctx, qkv, causal: bool, scale: float):
         _require_gpu_f32("qkv", qkv)
         qkv = qkv.contiguous()
@@ -246,7 +256,9 @@ class _AttnPackedFn(torch.autograd.Function):
         return o.view(B, N, H * D)
 
     @staticmethod
+    @_bwd
     def backward(ctx, do):
+        do = do.float()
         qkv, o, lse = ctx.saved_tensors
         B, N, _, H, D = qkv.shape
         do = do.contiguous().view(B, N, H, D)
@@ -261,6 +273,7 @@ class _AttnFn(torch.autograd.Function):
     """Separate q, k, v of shape (B, H, N, D) with arbitrary outer strides -> o (B, H, N, D)."""
 
     @staticmethod
+    @_fwd_f32
     def forward(ctx, q, k, v, causal: bool, scale: float):
         for n, t in (("q", q), ("k", k), ("v", v)):
             _require_gpu_f32(n, t)
@@ -272,9 +285,10 @@ class _AttnFn(torch.autograd.Function):
         return o
 
     @staticmethod
+    @_bwd
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        do = do.contiguous()
+        do = do.float().contiguous()
         dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
         _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, ctx.causal, ctx.scale)
         return dq, dk, dv, None, None

@@ -30,6 +30,7 @@ class FlashAttentionFunction(Function):
     do not change anything.  ``mask`` is not supported by the kernel and must be None."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, q, k, v, mask, causal, q_bucket_size, k_bucket_size):
         if mask is not None:
             raise NotImplementedError("key-padding masks are not implemented in the HIP attention kernel")
@@ -44,10 +45,11 @@ class FlashAttentionFunction(Function):
         return o
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, do):
         causal, scale = ctx.args
         q, k, v, o, lse = ctx.saved_tensors
-        do = do.contiguous()
+        do = do.float().contiguous()
         dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
         ops._attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale)
         return dq, dk, dv, None, None, None, None

@@ -96,3 +96,20 @@ def test_full_size_properties_vit_b_block():
     q2 = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x2)
     assert max_err(q2.cpu(), 2 * q1.cpu()) < 1e-5 * float(q1.abs().max() + 1)
     assert torch.isfinite(y).all()
+
+
+def test_bf16_autocast_keeps_kanvit_ops_in_fp32():
+    """bench.py --amp bf16: stock GEMMs in bf16, kanvit ops cast to fp32 at their boundary; the result stays
+    within bf16 rounding of the fp32 run (loose oracle, SURVEY.md section 7 'bf16 parity')."""
+    blob = load_npz("model_T_cheby.npz")
+    m = build(blob, "cheby")
+    x, labels = T(blob["x"]).to(DEV), T(blob["labels"]).to(DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = m(x)
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    assert max_err(logits.float().cpu(), T(blob["logits"])) < 5e-2
+    g = dict(m.named_parameters())["blocks.0.attn.q_mappings.0.cheby_coeffs"].grad
+    assert g.dtype == torch.float32 and torch.isfinite(g).all()
+    ref = grads_from(blob)["blocks.0.attn.q_mappings.0.cheby_coeffs"]
+    assert rel_err(g.cpu(), ref) < 5e-2
