@@ -28,13 +28,18 @@
 extern "C" {
 #endif
 
-#define KANVIT_ABI_VERSION 1
+#define KANVIT_ABI_VERSION 2
 
 /* error codes */
 #define KANVIT_OK 0
 #define KANVIT_EINVAL (-22)      /* bad descriptor / unsupported shape          */
 #define KANVIT_ENOMEM (-12)      /* workspace too small                         */
 #define KANVIT_EDEVICE (-5)      /* HIP runtime error (no device, launch error) */
+
+/* descriptor flags */
+#define KANVIT_FLAG_BF16_MFMA 1  /* contract on the bf16 matrix cores (operands rounded to bf16, fp32 accumulate, fp32
+                                    I/O); used for the bf16 configurations, never for the fp32 parity path.  Shapes
+                                    the bf16 kernels do not cover silently use the exact fp32 kernels.               */
 
 /* basis families: phi_g(x) generated on the fly, never stored in HBM */
 #define KANVIT_LINEAR 0   /* phi = x                               nn.Linear in attention.py:136-142           */
@@ -73,7 +78,7 @@ typedef struct kanvit_layer_desc {
     int32_t spline_order;  /* BSPLINE only                                                  */
     int32_t has_base;      /* BSPLINE / RBF: extra silu(x) column per input feature         */
     float rbf_inv_h;       /* RBF: 1 / denominator                                          */
-    int32_t reserved;
+    int32_t flags;         /* KANVIT_FLAG_*                                                  */
     int64_t M;             /* rows                                                          */
     int64_t ldx;           /* row stride (floats) of x and dx                               */
     int64_t ldu;           /* row stride of u and du (RBF; group g uses columns [g*I, +I))  */
@@ -85,8 +90,10 @@ typedef struct kanvit_layer_desc {
  * forward of models/cheby.py:36-48, models/effkan.py:174-187, models/fastkan.py:66-76 (the
  * LayerNorm of :68 is applied by the caller and passed as u; u = NULL means u = x),
  * models/nfkan.py:36-52, models/sinekan.py:81-91, and nn.Linear (attention.py:136-142).      */
+size_t kanvit_layer_fwd_workspace(const kanvit_layer_desc* d);   /* 0 unless KANVIT_FLAG_BF16_MFMA (repacked weights) */
 int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u, const float* w,
-                     const float* bparams, const float* bias, float* y, void* stream);
+                     const float* bparams, const float* bias, float* y, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 /* ---- backward w.r.t. the layer input (what torch.autograd derives for the reference) ------
  * dx[m, c*I + i] = sum over the groups g with g % x_group_mod == c of
@@ -94,9 +101,10 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
  * RBF: du[m, g*I+i] gets the spline-path gradient, dx the base-path gradient.
  * SINE: dparam receives per-row-tile partial sums of d loss / d freq, shape
  *       [kanvit_layer_dparam_tiles(d)][groups][G]; the caller sums over dim 0.                */
+size_t kanvit_layer_bwd_input_workspace(const kanvit_layer_desc* d);   /* 0 unless KANVIT_FLAG_BF16_MFMA */
 int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const float* u, const float* w,
                            const float* bparams, const float* dy, float* dx, float* du, float* dparam,
-                           void* stream);
+                           void* workspace, size_t workspace_bytes, void* stream);
 int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d);
 
 /* ---- backward w.r.t. the packed weights ---------------------------------------------------
@@ -139,15 +147,16 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
  * heads' q, k and v mappings).                                                                 */
 #define KANVIT_DECLARE_FAMILY(name)                                                                           \
     int kanvit_##name##_fwd(const kanvit_layer_desc*, const float*, const float*, const float*, const float*, \
-                            const float*, float*, void*);                                                     \
+                            const float*, float*, void*, size_t, void*);                                      \
     int kanvit_##name##_bwd_input(const kanvit_layer_desc*, const float*, const float*, const float*,         \
-                                  const float*, const float*, float*, float*, float*, void*);                 \
+                                  const float*, const float*, float*, float*, float*, void*, size_t, void*);  \
     int kanvit_##name##_bwd_weight(const kanvit_layer_desc*, const float*, const float*, const float*,        \
                                    const float*, float*, void*, size_t, void*);                               \
     int kanvit_##name##_qkv_fwd(const kanvit_layer_desc*, const float*, const float*, const float*,           \
-                                const float*, const float*, float*, void*);                                   \
+                                const float*, const float*, float*, void*, size_t, void*);                    \
     int kanvit_##name##_qkv_bwd_input(const kanvit_layer_desc*, const float*, const float*, const float*,     \
-                                      const float*, const float*, float*, float*, float*, void*);             \
+                                      const float*, const float*, float*, float*, float*, void*, size_t,      \
+                                      void*);                                                                 \
     int kanvit_##name##_qkv_bwd_weight(const kanvit_layer_desc*, const float*, const float*, const float*,    \
                                        const float*, float*, void*, size_t, void*);
 KANVIT_DECLARE_FAMILY(linear)

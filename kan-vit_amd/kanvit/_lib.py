@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkanvit.so")
 
 LINEAR, CHEBY, BSPLINE, RBF, SINE, FOURIER = range(6)
+FLAG_BF16_MFMA = 1
 FAMILY_NAMES = ["linear", "cheby", "bspline", "rbf", "sine", "fourier"]
 
 
@@ -26,7 +27,7 @@ class KanvitError(RuntimeError):
 class LayerDesc(C.Structure):
     _fields_ = [("family", C.c_int32), ("groups", C.c_int32), ("x_group_mod", C.c_int32), ("I", C.c_int32),
                 ("O", C.c_int32), ("G", C.c_int32), ("spline_order", C.c_int32), ("has_base", C.c_int32),
-                ("rbf_inv_h", C.c_float), ("reserved", C.c_int32), ("M", C.c_int64), ("ldx", C.c_int64),
+                ("rbf_inv_h", C.c_float), ("flags", C.c_int32), ("M", C.c_int64), ("ldx", C.c_int64),
                 ("ldu", C.c_int64), ("ldy", C.c_int64), ("bparam_stride", C.c_int64)]
 
 
@@ -40,8 +41,8 @@ class AttnDesc(C.Structure):
 
 
 _P = C.c_void_p
-_LAYER_FWD = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P]
-_LAYER_BWD_IN = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]
+_LAYER_FWD = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]
+_LAYER_BWD_IN = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]
 _LAYER_BWD_W = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, C.c_size_t, _P]
 
 # every symbol include/kanvit.h declares: name -> (restype, argtypes)
@@ -49,6 +50,8 @@ SYMBOLS = {
     "kanvit_abi_version": (C.c_int, []),
     "kanvit_last_error": (C.c_char_p, []),
     "kanvit_device_count": (C.c_int, []),
+    "kanvit_layer_fwd_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
+    "kanvit_layer_bwd_input_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_fwd": (C.c_int, _LAYER_FWD),
     "kanvit_layer_bwd_input": (C.c_int, _LAYER_BWD_IN),
     "kanvit_layer_dparam_tiles": (C.c_int64, [C.POINTER(LayerDesc)]),
@@ -82,7 +85,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.kanvit_abi_version() != 1:
+        if handle.kanvit_abi_version() != 2:
             raise KanvitError("libkanvit.so ABI version mismatch")
         _lib = handle
     return _lib

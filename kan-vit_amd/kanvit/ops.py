@@ -28,6 +28,7 @@ class LayerCfg:
     spline_order: int = 0
     has_base: int = 0
     rbf_inv_h: float = 0.0
+    flags: int = 0          # _lib.FLAG_BF16_MFMA: contract on the bf16 matrix cores (set under bf16 autocast)
 
     @property
     def GP(self) -> int:
@@ -108,7 +109,12 @@ def _require_gpu_f32(name: str, t: Optional[torch.Tensor]):
 
 def _desc(cfg: LayerCfg, M: int, ldx: int, ldu: int, ldy: int, bp_stride: int) -> LayerDesc:
     return LayerDesc(cfg.family, cfg.groups, cfg.x_group_mod, cfg.I, cfg.O, cfg.G, cfg.spline_order, cfg.has_base,
-                     cfg.rbf_inv_h, 0, M, ldx, ldu, ldy, bp_stride)
+                     cfg.rbf_inv_h, cfg.flags, M, ldx, ldu, ldy, bp_stride)
+
+
+def _workspace(nbytes: int, device):
+    """Caller-owned scratch for a C-ABI call (16-byte aligned by the torch allocator)."""
+    return torch.empty(max((nbytes + 3) // 4, 4), device=device, dtype=torch.float32)
 
 
 _fwd_f32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -139,10 +145,13 @@ class _KanLayerFn(torch.autograd.Function):
             raise KanvitError(f"u shape {tuple(u.shape)} != {(M, cfg.groups * cfg.I)}")
         y = torch.empty(M, cfg.groups * cfg.O, device=x.device, dtype=torch.float32)
         d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, 0 if bparams is None else bparams.shape[1])
-        tag = ("qkv" if cfg.groups > 1 else "layer") + "_fwd"
-        with torch.cuda.device(x.device), _timed(tag, *_layer_cost(cfg, M, "fwd")):
-            check(_lib.lib().kanvit_layer_fwd(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(bias),
-                                              _ptr(y), _stream()), "kanvit_layer_fwd")
+        tag = ("qkv" if cfg.groups > 1 else "layer") + "_fwd" + ("_bf16" if cfg.flags & _lib.FLAG_BF16_MFMA else "")
+        with torch.cuda.device(x.device):
+            nbytes = int(_lib.lib().kanvit_layer_fwd_workspace(C.byref(d)))
+            ws = _workspace(nbytes, x.device) if nbytes else None
+            with _timed(tag, *_layer_cost(cfg, M, "fwd")):
+                check(_lib.lib().kanvit_layer_fwd(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(bias),
+                                                  _ptr(y), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_fwd")
         ctx.cfg = cfg
         ctx.has_u = u is not None
         ctx.has_bp = bparams is not None
@@ -171,10 +180,12 @@ class _KanLayerFn(torch.autograd.Function):
                 if cfg.family == SINE:
                     tiles = int(L.kanvit_layer_dparam_tiles(C.byref(d)))
                     dpart = torch.empty(tiles, cfg.groups, cfg.G, device=x.device, dtype=torch.float32)
+                nb_in = int(L.kanvit_layer_bwd_input_workspace(C.byref(d)))
+                ws_in = _workspace(nb_in, x.device) if nb_in else None
                 with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_input", *_layer_cost(cfg, M, "bwd_input")):
                     check(L.kanvit_layer_bwd_input(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(dy),
-                                                   _ptr(dx), _ptr(du_buf), _ptr(dpart), _stream()),
-                          "kanvit_layer_bwd_input")
+                                                   _ptr(dx), _ptr(du_buf), _ptr(dpart), _ptr(ws_in), C.c_size_t(nb_in),
+                                                   _stream()), "kanvit_layer_bwd_input")
                 if cfg.family == RBF:
                     if ctx.has_u:
                         du = du_buf
@@ -198,7 +209,13 @@ class _KanLayerFn(torch.autograd.Function):
 
 def kan_layer(x: torch.Tensor, w: torch.Tensor, cfg: LayerCfg, u: Optional[torch.Tensor] = None,
               bparams: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Fused basis + contraction for `cfg.groups` layers sharing the rows of x (see include/kanvit.h)."""
+    """Fused basis + contraction for `cfg.groups` layers sharing the rows of x (see include/kanvit.h).
+
+    Under ``torch.autocast('cuda', dtype=torch.bfloat16)`` the contraction is allowed onto the bf16 matrix cores
+    (KANVIT_FLAG_BF16_MFMA); without autocast it is always the exact fp32 path."""
+    if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not (cfg.flags & 1):
+        from dataclasses import replace
+        cfg = replace(cfg, flags=cfg.flags | _lib.FLAG_BF16_MFMA)
     return _KanLayerFn.apply(x, u, w, bparams, bias, cfg)
 
 

@@ -50,24 +50,28 @@ def test_descriptor_layout_and_errors(lib):
     from kanvit import _lib
     assert ctypes.sizeof(_lib.LayerDesc) == 10 * 4 + 5 * 8
     assert ctypes.sizeof(_lib.AttnDesc) == 6 * 4 + 12 * 8
-    assert lib.kanvit_abi_version() == 1
+    assert lib.kanvit_abi_version() == 2
     d = _lib.LayerDesc(family=99, groups=1, x_group_mod=1, I=4, O=3, G=1, M=6, ldx=4, ldy=3)
-    rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
+    rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
     assert rc == -22 and b"family" in lib.kanvit_last_error()
     d.family = _lib.CHEBY
     d.G = 5
-    rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None)
+    rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
     assert rc == -22 and b"null" in lib.kanvit_last_error()
     d.G = 100
-    assert lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -22
+    assert lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -22
     d.G = 5
-    assert lib.kanvit_cheby_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -22
-    assert lib.kanvit_sine_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -22
+    assert lib.kanvit_cheby_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -22
+    assert lib.kanvit_sine_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -22
     assert b"mismatch" in lib.kanvit_last_error()
     # workspace sizing is a pure host function
     d.M, d.I, d.O, d.groups, d.x_group_mod, d.ldx, d.ldy = 25216, 64, 64, 36, 12, 768, 2304
     ws = lib.kanvit_layer_bwd_weight_workspace(ctypes.byref(d))
     assert ws % (36 * 320 * 64 * 4) == 0 and ws > 0
+    assert lib.kanvit_layer_fwd_workspace(ctypes.byref(d)) == 0            # exact fp32 path needs no scratch
+    d.flags = _lib.FLAG_BF16_MFMA
+    assert lib.kanvit_layer_fwd_workspace(ctypes.byref(d)) == 36 * 320 * 64 * 2   # bf16 repack of the weights
+    d.flags = 0
     a = _lib.AttnDesc(B=2, H=3, N=300, D=64, scale=0.125)
     assert lib.kanvit_attn_fwd(ctypes.byref(a), None, None, None, None, None, None) == -22
     a.N, a.D = 197, 63

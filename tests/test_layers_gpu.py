@@ -144,3 +144,20 @@ def test_grouped_qkv_equals_per_layer_oracle(fam, geom):
     msa = msa.to(DEV)
     got = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x.to(DEV).reshape(b * n, d)).cpu()
     assert max_err(got, want) < FWD_TOL * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("fam", ["vanilla", "cheby", "efficientkan", "fast", "sine"])
+def test_bf16_mfma_forward_close_to_fp32(fam):
+    """KANVIT_FLAG_BF16_MFMA (set under bf16 autocast): operands rounded to bf16, fp32 accumulate.  Loose
+    tolerance against the exact path (bf16 configs are judged at ~1e-2 relative)."""
+    from attention import MSA
+    from kanvit import grouped
+    torch.manual_seed(2)
+    msa = MSA(256, 4, type=fam).to(DEV)
+    x = torch.randn(4 * 197, 256, device=DEV)
+    exact = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        fast = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+    assert fast.dtype == torch.float32
+    err = float((fast - exact).abs().max()) / float(exact.abs().max())
+    assert 0 < err < 2e-2, (fam, err)          # > 0: the bf16 kernel really ran
