@@ -199,7 +199,8 @@ class _KanLayerFn(torch.autograd.Function):
                 dw = torch.empty_like(w)
                 nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(d)))
                 ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_weight", *_layer_cost(cfg, M, "bwd_weight")):
+                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_weight" + ("_bf16" if cfg.flags & 1 else ""),
+                            *_layer_cost(cfg, M, "bwd_weight")):
                     check(L.kanvit_layer_bwd_weight(C.byref(d), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(dw),
                                                     _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
             if need_b and ctx.has_bias:
