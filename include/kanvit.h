@@ -126,6 +126,8 @@ typedef struct kanvit_attn_desc {
     int32_t B, H, N, D;
     int32_t causal;         /* utils.py:177-180 with equal q/k lengths */
     float scale;            /* D^-1/2 in both callers */
+    int32_t flags;          /* KANVIT_FLAG_BF16_MFMA: products on the bf16 matrix cores (needs D % 16 == 0) */
+    int32_t reserved;
     int64_t q_stride_b, q_stride_h, q_stride_n;
     int64_t k_stride_b, k_stride_h, k_stride_n;
     int64_t v_stride_b, v_stride_h, v_stride_n;

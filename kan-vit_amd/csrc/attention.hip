@@ -18,10 +18,52 @@
 // D..32*DT-1 and rows N..NP-1 are zero.
 #include "kanvit_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int ATHR = 256;
 constexpr float LOG2E = 1.4426950408889634f;
+
+// ---- bf16 matrix-core mode (KANVIT_FLAG_BF16_MFMA): operands gathered from the fp32 LDS tiles / accumulators, rounded to
+// bf16, contracted by v_mfma_f32_32x32x16_bf16 (16 k per instruction instead of 2).  k-slot e of lane half h is
+//   * the (8h+e)-th of 16 consecutive head-dim positions when the operand comes from LDS rows, or
+//   * accumulator register 8s+e, i.e. tile row 16s + 8(e>>2) + 4h + (e&3), when a score tile feeds the second product
+//     (cdna guide section 3, "accumulator tile as the next MFMA's operand"); the LDS operand then reads the SAME rows.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned kv_pk(float lo, float hi) {
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16x8_t kv_pack8(const float (&f)[8]) {
+    const u32x4 u = {kv_pk(f[0], f[1]), kv_pk(f[2], f[3]), kv_pk(f[4], f[5]), kv_pk(f[6], f[7])};
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+// 8 consecutive floats of one LDS row
+__device__ __forceinline__ bf16x8_t kv_row8(const float* __restrict__ p) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = p[e];
+    return kv_pack8(f);
+}
+// one column of the 8 tile rows that accumulator registers 8s..8s+7 of lane half hf stand for; p -> (row 16s + 4hf, col)
+__device__ __forceinline__ bf16x8_t kv_col8(const float* __restrict__ p, int stride) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = p[e * stride];
+        f[4 + e] = p[(8 + e) * stride];
+    }
+    return kv_pack8(f);
+}
+__device__ __forceinline__ bf16x8_t kv_acc8(const f32x16& a, int s) {
+    const u32x4 u = {kv_pk(a[8 * s], a[8 * s + 1]), kv_pk(a[8 * s + 2], a[8 * s + 3]), kv_pk(a[8 * s + 4], a[8 * s + 5]),
+                     kv_pk(a[8 * s + 6], a[8 * s + 7])};
+    return __builtin_bit_cast(bf16x8_t, u);
+}
 
 struct AttnArgs {
     const float* q;
@@ -41,6 +83,7 @@ struct AttnArgs {
     int B, H, N, D, causal, nkt, vec;
     float scale;
 };
+
 
 // Fill dst[rows][KS] from src rows row0.. (row stride stride_n), zero-padding rows >= N and columns
 // >= D.  VEC path (D, strides and base 16-byte aligned): float4 global loads, four passes issued
@@ -114,7 +157,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dstg, long long s
 // =============================================================================================
 // forward: grid B*H.  NKT = compile-time bound on the number of 32-key tiles (registers).
 // =============================================================================================
-template <int DT, int NKT>
+template <int DT, int NKT, bool BF>
 __global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 32 * DT + 1;
@@ -140,9 +183,15 @@ __global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
         load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();                     // also covers the K/V fill on the first trip
 
-        float qf[16 * DT];
+        float qf[BF ? 1 : 16 * DT];
+        bf16x8_t qb[BF ? 2 * DT : 1];
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) qf[s] = Q_w[l31 * KS + 2 * s + hf];
+            for (int ks = 0; ks < 2 * DT; ++ks) qb[ks] = kv_row8(Q_w + l31 * KS + 16 * ks + 8 * hf);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) qf[s] = Q_w[l31 * KS + 2 * s + hf];
+        }
 
         // S^T tiles: rows = keys, cols = queries
         f32x16 sacc[NKT];
@@ -151,10 +200,17 @@ __global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
             if (j < nkt) {
-                const float* kp = K_s + (j * 32 + l31) * KS + hf;
+                if constexpr (BF) {
+                    const float* kp = K_s + (j * 32 + l31) * KS + 8 * hf;
 #pragma unroll
-                for (int s = 0; s < 16 * DT; ++s)
-                    sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc[j], 0, 0, 0);
+                    for (int ks = 0; ks < 2 * DT; ++ks)
+                        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_row8(kp + 16 * ks), qb[ks], sacc[j], 0, 0, 0);
+                } else {
+                    const float* kp = K_s + (j * 32 + l31) * KS + hf;
+#pragma unroll
+                    for (int s = 0; s < 16 * DT; ++s)
+                        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc[j], 0, 0, 0);
+                }
             }
         }
         // softmax over keys: registers of this lane + the partner lane in the other half
@@ -199,13 +255,26 @@ __global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < NKT; ++j) {
             if (j < nkt) {
+                if constexpr (BF) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = sacc[j][r] * inv;
-                    const float* vp = V_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+                    for (int r = 0; r < 16; ++r) sacc[j][r] *= inv;
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], pv, oacc[dt], 0, 0, 0);
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8_t pb = kv_acc8(sacc[j], s2);
+                        const float* vp = V_s + (j * 32 + 16 * s2 + 4 * hf) * KS + l31;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+                            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_col8(vp + dt * 32, KS), pb, oacc[dt], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = sacc[j][r] * inv;
+                        const float* vp = V_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+                            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], pv, oacc[dt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -252,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
 // dK^T / dV^T in accumulators) and sweeps all query tiles; S and dP are computed with the key
 // on the lane so they feed the second products as B operands straight from registers.
 // =============================================================================================
-template <int DT>
+template <int DT, bool BF>
 __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 32 * DT + 1;
@@ -286,16 +355,27 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
         const int key = jt * 32 + l31;
         const bool key_ok = (jt < nkt) && (key < N);
         // K and V fragments of this wave's keys (B operands): stage through the wave's tile
-        float kf[16 * DT], vf[16 * DT];
+        float kf[BF ? 1 : 16 * DT], vf[BF ? 1 : 16 * DT];
+        bf16x8_t kbf[BF ? 2 * DT : 1], vbf[BF ? 2 * DT : 1];
         load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
+            for (int ks = 0; ks < 2 * DT; ++ks) kbf[ks] = kv_row8(T_w + l31 * KS + 16 * ks + 8 * hf);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
+        }
         __syncthreads();
         load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
+            for (int ks = 0; ks < 2 * DT; ++ks) vbf[ks] = kv_row8(T_w + l31 * KS + 16 * ks + 8 * hf);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
+        }
 
         f32x16 dkacc[DT], dvacc[DT];
 #pragma unroll
@@ -313,12 +393,22 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
                 sacc[r] = 0.0f;
                 pacc[r] = 0.0f;
             }
-            const float* qp = Q_s + (qt * 32 + l31) * KS + hf;
-            const float* dp = dO_s + (qt * 32 + l31) * KS + hf;
+            if constexpr (BF) {
+                const float* qp = Q_s + (qt * 32 + l31) * KS + 8 * hf;
+                const float* dp = dO_s + (qt * 32 + l31) * KS + 8 * hf;
 #pragma unroll
-            for (int s = 0; s < 16 * DT; ++s) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * s], kf[s], sacc, 0, 0, 0);    // S[q][key]
-                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[2 * s], vf[s], pacc, 0, 0, 0);    // dP[q][key]
+                for (int ks = 0; ks < 2 * DT; ++ks) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_row8(qp + 16 * ks), kbf[ks], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_row8(dp + 16 * ks), vbf[ks], pacc, 0, 0, 0);
+                }
+            } else {
+                const float* qp = Q_s + (qt * 32 + l31) * KS + hf;
+                const float* dp = dO_s + (qt * 32 + l31) * KS + hf;
+#pragma unroll
+                for (int s = 0; s < 16 * DT; ++s) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * s], kf[s], sacc, 0, 0, 0);    // S[q][key]
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[2 * s], vf[s], pacc, 0, 0, 0);    // dP[q][key]
+                }
             }
             // p = exp(s*scale - lse), ds = p * scale * (dp - delta)        (utils.py:278-287)
 #pragma unroll
@@ -330,13 +420,26 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
                 pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+            if constexpr (BF) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (qt * 32 + kv_acc_row(r, hf)) * KS + l31;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t pb = kv_acc8(sacc, s2), db = kv_acc8(pacc, s2);
+                    const int row = (qt * 32 + 16 * s2 + 4 * hf) * KS + l31;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dO_s[row + dt * 32], sacc[r], dvacc[dt], 0, 0, 0);
-                    dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Q_s[row + dt * 32], pacc[r], dkacc[dt], 0, 0, 0);
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_col8(dO_s + row + dt * 32, KS), pb, dvacc[dt], 0, 0, 0);
+                        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_col8(Q_s + row + dt * 32, KS), db, dkacc[dt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (qt * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dO_s[row + dt * 32], sacc[r], dvacc[dt], 0, 0, 0);
+                        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Q_s[row + dt * 32], pacc[r], dkacc[dt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -362,7 +465,7 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_kv_kernel(const AttnArgs a) {
 // =============================================================================================
 // backward dQ: query-stationary mirror of the forward kernel.
 // =============================================================================================
-template <int DT>
+template <int DT, bool BF>
 __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 32 * DT + 1;
@@ -388,16 +491,27 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
         const int qt = it * 4 + wave;
         const int qrow = qt * 32 + l31;
         const bool q_ok = (qt < nkt) && (qrow < N);
-        float qf[16 * DT], dof[16 * DT];
+        float qf[BF ? 1 : 16 * DT], dof[BF ? 1 : 16 * DT];
+        bf16x8_t qbf[BF ? 2 * DT : 1], dobf[BF ? 2 * DT : 1];
         load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
+            for (int ks = 0; ks < 2 * DT; ++ks) qbf[ks] = kv_row8(T_w + l31 * KS + 16 * ks + 8 * hf);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
+        }
         __syncthreads();
         load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < nkt) ? N : 0, D, lane, 64, a.vec);
         __syncthreads();
+        if constexpr (BF) {
 #pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
+            for (int ks = 0; ks < 2 * DT; ++ks) dobf[ks] = kv_row8(T_w + l31 * KS + 16 * ks + 8 * hf);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
+        }
         const float lse2 = q_ok ? a.lse_in[(long long)bh * N + qrow] * LOG2E : INFINITY;
         const float dl = q_ok ? a.delta_in[(long long)bh * N + qrow] : 0.0f;
 
@@ -414,12 +528,22 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
                 sacc[r] = 0.0f;
                 pacc[r] = 0.0f;
             }
-            const float* kp = K_s + (j * 32 + l31) * KS + hf;
-            const float* vp = V_s + (j * 32 + l31) * KS + hf;
+            if constexpr (BF) {
+                const float* kp = K_s + (j * 32 + l31) * KS + 8 * hf;
+                const float* vp = V_s + (j * 32 + l31) * KS + 8 * hf;
 #pragma unroll
-            for (int s = 0; s < 16 * DT; ++s) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc, 0, 0, 0);    // S^T[key][q]
-                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], dof[s], pacc, 0, 0, 0);   // dP^T[key][q]
+                for (int ks = 0; ks < 2 * DT; ++ks) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_row8(kp + 16 * ks), qbf[ks], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_row8(vp + 16 * ks), dobf[ks], pacc, 0, 0, 0);
+                }
+            } else {
+                const float* kp = K_s + (j * 32 + l31) * KS + hf;
+                const float* vp = V_s + (j * 32 + l31) * KS + hf;
+#pragma unroll
+                for (int s = 0; s < 16 * DT; ++s) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc, 0, 0, 0);    // S^T[key][q]
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], dof[s], pacc, 0, 0, 0);   // dP^T[key][q]
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -429,12 +553,23 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
                 pacc[r] = p * a.scale * (pacc[r] - dl);                                          // dS^T
             }
             // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            if constexpr (BF) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* kr = K_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t db = kv_acc8(pacc, s2);
+                    const float* kr = K_s + (j * 32 + 16 * s2 + 4 * hf) * KS + l31;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[dt * 32], pacc[r], dqacc[dt], 0, 0, 0);
+                    for (int dt = 0; dt < DT; ++dt)
+                        dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kv_col8(kr + dt * 32, KS), db, dqacc[dt], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* kr = K_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[dt * 32], pacc[r], dqacc[dt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -476,30 +611,30 @@ AttnArgs make_args(const kanvit_attn_desc* d) {
     return a;
 }
 
-template <int DT, int NKT>
+template <int DT, int NKT, bool BF>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
     constexpr int KS = 32 * DT + 1;
     const size_t lds = sizeof(float) * ((size_t)2 * a.nkt * 32 * KS + (size_t)4 * 32 * KS);
     static bool attr_done = false;
     if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(attn_fwd_kernel<DT, NKT>, 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds(attn_fwd_kernel<DT, NKT, BF>, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<DT, NKT>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds, st, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, NKT, BF>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds, st, a);
     KV_LAUNCH_CHECK("attn_fwd_kernel");
     return 0;
 }
 
-template <int DT>
+template <int DT, bool BF>
 int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
-    if (a.nkt <= 1) return launch_fwd<DT, 1>(a, st);
-    if (a.nkt <= 2) return launch_fwd<DT, 2>(a, st);
-    if (a.nkt <= 4) return launch_fwd<DT, 4>(a, st);
-    if (a.nkt <= 7) return launch_fwd<DT, 7>(a, st);
-    return launch_fwd<DT, 8>(a, st);
+    if (a.nkt <= 1) return launch_fwd<DT, 1, BF>(a, st);
+    if (a.nkt <= 2) return launch_fwd<DT, 2, BF>(a, st);
+    if (a.nkt <= 4) return launch_fwd<DT, 4, BF>(a, st);
+    if (a.nkt <= 7) return launch_fwd<DT, 7, BF>(a, st);
+    return launch_fwd<DT, 8, BF>(a, st);
 }
 
-template <int DT>
+template <int DT, bool BF>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
     constexpr int KS = 32 * DT + 1;
     const int NP = a.nkt * 32;
@@ -507,13 +642,13 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
     const size_t lds_q = sizeof(float) * ((size_t)2 * NP * KS + (size_t)4 * 32 * KS);
     static bool attr_done = false;
     if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(attn_bwd_kv_kernel<DT>, 160 * 1024));
-        KV_HIP_CHECK(kv_allow_lds(attn_bwd_q_kernel<DT>, 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv_kernel<DT, BF>), 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds((attn_bwd_q_kernel<DT, BF>), 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kv_kernel<DT>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_kv, st, a);
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_kv, st, a);
     KV_LAUNCH_CHECK("attn_bwd_kv_kernel");
-    hipLaunchKernelGGL((attn_bwd_q_kernel<DT>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_q, st, a);
+    hipLaunchKernelGGL((attn_bwd_q_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_q, st, a);
     KV_LAUNCH_CHECK("attn_bwd_q_kernel");
     return 0;
 }
@@ -531,7 +666,9 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
     a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-    return d->D <= 32 ? dispatch_fwd<1>(a, st) : dispatch_fwd<2>(a, st);
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !getenv("KANVIT_NO_BF16"))
+        return d->D <= 32 ? dispatch_fwd<1, true>(a, st) : dispatch_fwd<2, true>(a, st);
+    return d->D <= 32 ? dispatch_fwd<1, false>(a, st) : dispatch_fwd<2, false>(a, st);
 }
 
 size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d) {
@@ -559,7 +696,9 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     const long long rows = (long long)d->B * d->H * d->N;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
     KV_LAUNCH_CHECK("attn_delta_kernel");
-    return d->D <= 32 ? launch_bwd<1>(a, st) : launch_bwd<2>(a, st);
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !getenv("KANVIT_NO_BF16"))
+        return d->D <= 32 ? launch_bwd<1, true>(a, st) : launch_bwd<2, true>(a, st);
+    return d->D <= 32 ? launch_bwd<1, false>(a, st) : launch_bwd<2, false>(a, st);
 }
 
 }  // extern "C"

@@ -33,7 +33,7 @@ class LayerDesc(C.Structure):
 
 class AttnDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("causal", C.c_int32),
-                ("scale", C.c_float),
+                ("scale", C.c_float), ("flags", C.c_int32), ("reserved", C.c_int32),
                 ("q_stride_b", C.c_int64), ("q_stride_h", C.c_int64), ("q_stride_n", C.c_int64),
                 ("k_stride_b", C.c_int64), ("k_stride_h", C.c_int64), ("k_stride_n", C.c_int64),
                 ("v_stride_b", C.c_int64), ("v_stride_h", C.c_int64), ("v_stride_n", C.c_int64),

@@ -223,36 +223,39 @@ def kan_layer(x: torch.Tensor, w: torch.Tensor, cfg: LayerCfg, u: Optional[torch
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def _attn_desc(q, k, v, o, causal: bool, scale: float) -> AttnDesc:
+_attn_flags = 0      # set by attention()/attention_packed() from the ambient autocast state (the Functions run with autocast off)
+
+
+def _attn_desc(q, k, v, o, causal: bool, scale: float, flags: int = 0) -> AttnDesc:
     B, H, N, D = q.shape
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
         if t.stride(3) != 1:
             raise KanvitError(f"{n}: innermost dimension must be contiguous")
-    return AttnDesc(B, H, N, D, int(bool(causal)), float(scale),
+    return AttnDesc(B, H, N, D, int(bool(causal)), float(scale), int(flags), 0,
                     q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                     v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2))
 
 
-def _attn_fwd(q, k, v, o, causal, scale):
+def _attn_fwd(q, k, v, o, causal, scale, flags=0):
     B, H, N, _ = q.shape
     lse = torch.empty(B, H, N, device=q.device, dtype=torch.float32)
-    d = _attn_desc(q, k, v, o, causal, scale)
+    d = _attn_desc(q, k, v, o, causal, scale, flags)
     flops, nbytes = 4 * B * H * N * N * q.shape[3], 4 * 4 * B * H * N * q.shape[3]
-    with torch.cuda.device(q.device), _timed("attn_fwd", flops, nbytes):
+    with torch.cuda.device(q.device), _timed("attn_fwd" + ("_bf16" if flags & 1 else ""), flops, nbytes):
         check(_lib.lib().kanvit_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()),
               "kanvit_attn_fwd")
     return lse
 
 
-def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale):
-    d = _attn_desc(q, k, v, o, causal, scale)
+def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale, flags=0):
+    d = _attn_desc(q, k, v, o, causal, scale, flags)
     if (do.stride() != o.stride()) or dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != v.stride():
         raise KanvitError("attention backward: gradient layouts must match their forward tensors")
     L = _lib.lib()
     nbytes = int(L.kanvit_attn_bwd_workspace(C.byref(d)))
     ws = torch.empty(max(nbytes // 4, 1), device=q.device, dtype=torch.float32)
     B, H, N, D = q.shape
-    with torch.cuda.device(q.device), _timed("attn_bwd", 14 * B * H * N * N * D, 4 * 9 * B * H * N * D):
+    with torch.cuda.device(q.device), _timed("attn_bwd" + ("_bf16" if flags & 1 else ""), 14 * B * H * N * N * D, 4 * 9 * B * H * N * D):
         check(L.kanvit_attn_bwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(do), _ptr(dq), _ptr(dk),
                                 _ptr(dv), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_attn_bwd")
 
@@ -262,15 +265,15 @@ class _AttnPackedFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd_f32
-    def forward(ctx, qkv, causal: bool, scale: float):
+    def forward(ctx, qkv, causal: bool, scale: float, flags: int = 0):
         _require_gpu_f32("qkv", qkv)
         qkv = qkv.contiguous()
         B, N, three, H, D = qkv.shape
         q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         o = torch.empty(B, N, H, D, device=qkv.device, dtype=torch.float32)
-        lse = _attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal, scale)
+        lse = _attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal, scale, flags)
         ctx.save_for_backward(qkv, o, lse)
-        ctx.causal, ctx.scale = causal, scale
+        ctx.causal, ctx.scale, ctx.flags = causal, scale, flags
         return o.view(B, N, H * D)
 
     @staticmethod
@@ -283,8 +286,8 @@ class _AttnPackedFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        _attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do.permute(0, 2, 1, 3), dq, dk, dv, ctx.causal, ctx.scale)
-        return dqkv, None, None
+        _attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do.permute(0, 2, 1, 3), dq, dk, dv, ctx.causal, ctx.scale, ctx.flags)
+        return dqkv, None, None, None
 
 
 class _AttnFn(torch.autograd.Function):
@@ -292,14 +295,14 @@ class _AttnFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd_f32
-    def forward(ctx, q, k, v, causal: bool, scale: float):
+    def forward(ctx, q, k, v, causal: bool, scale: float, flags: int = 0):
         for n, t in (("q", q), ("k", k), ("v", v)):
             _require_gpu_f32(n, t)
         q, k, v = (t if t.stride(3) == 1 else t.contiguous() for t in (q, k, v))
         o = torch.empty(q.shape, device=q.device, dtype=torch.float32)
-        lse = _attn_fwd(q, k, v, o, causal, scale)
+        lse = _attn_fwd(q, k, v, o, causal, scale, flags)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.causal, ctx.scale = causal, scale
+        ctx.causal, ctx.scale, ctx.flags = causal, scale, flags
         return o
 
     @staticmethod
@@ -308,14 +311,20 @@ class _AttnFn(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         do = do.float().contiguous()
         dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
-        _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, ctx.causal, ctx.scale)
-        return dq, dk, dv, None, None
+        _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, ctx.causal, ctx.scale, ctx.flags)
+        return dq, dk, dv, None, None, None
+
+
+def _autocast_flags() -> int:
+    """bf16 autocast allows the products onto the bf16 matrix cores; otherwise the exact fp32 kernels run."""
+    on = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    return _lib.FLAG_BF16_MFMA if on else 0
 
 
 def attention_packed(qkv: torch.Tensor, causal: bool = False, scale: Optional[float] = None) -> torch.Tensor:
-    return _AttnPackedFn.apply(qkv, causal, qkv.shape[-1] ** -0.5 if scale is None else scale)
+    return _AttnPackedFn.apply(qkv, causal, qkv.shape[-1] ** -0.5 if scale is None else scale, _autocast_flags())
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False,
               scale: Optional[float] = None) -> torch.Tensor:
-    return _AttnFn.apply(q, k, v, causal, q.shape[-1] ** -0.5 if scale is None else scale)
+    return _AttnFn.apply(q, k, v, causal, q.shape[-1] ** -0.5 if scale is None else scale, _autocast_flags())

@@ -85,3 +85,22 @@ def test_bitwise_reproducible():
         res.append((o.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,d", [(50, 32), (197, 64), (17, 16)])
+def test_bf16_mfma_attention_close_to_fp32(n, d):
+    from kanvit import ops
+    torch.manual_seed(3)
+    q, k, v = (torch.randn(2, 3, n, d, device=DEV, requires_grad=True) for _ in range(3))
+    do = torch.randn(2, 3, n, d, device=DEV)
+    outs = []
+    for amp in (False, True):
+        for t in (q, k, v):
+            t.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            o = ops.attention(q, k, v)
+        o.backward(do)
+        outs.append((o.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone()))
+    for a, b in zip(outs[1], outs[0]):
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        assert 0 < err < 3e-2, err
