@@ -49,6 +49,7 @@ struct LayerArgs {
     float* dparam;
     float* slab;
     const unsigned short* wb;   // bf16 fragment-major repack of w (KANVIT_FLAG_BF16_MFMA)
+    const unsigned short* wb2;  // bf16 repack for the input-gradient kernel: [g][chunk][O/8][KCT][8 n]
     long long M, ldx, ldu, ldy, bp_stride, rows_per_split;
     int I, O, groups, xmod, G, GP, order, nk, has_base, K, IC, msplit, nchunks_n;
     float rbf_inv_h;
@@ -405,6 +406,25 @@ __global__ __launch_bounds__(256) void kan_pack_w_fwd_kernel(const float* __rest
     *reinterpret_cast<u32x4*>(wb + e * 8) = out;
 }
 
+// w[groups][K][O] fp32 -> wb2[groups][nci][O/8][KCT][8] bf16: element (nb, kk, e) = w[g][ci*KC + kk][nb*8 + e]
+__global__ __launch_bounds__(256) void kan_pack_w_bwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb2,
+                                                             int K, int O, int KC, int KCT, int nci, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (g, ci, nb, kk) per thread
+    if (e >= total) return;
+    const int kk = (int)(e % KCT);
+    long long r = e / KCT;
+    const int nb = (int)(r % (O / 8));
+    r /= (O / 8);
+    const int ci = (int)(r % nci);
+    const long long g = r / nci;
+    const int k = ci * KC + kk;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (kk < KC && k < K) ? w[(g * K + k) * O + nb * 8 + j] : 0.0f;
+    u32x4 out = {kv_pack_bf16(v[0], v[1]), kv_pack_bf16(v[2], v[3]), kv_pack_bf16(v[4], v[5]), kv_pack_bf16(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(wb2 + e * 8) = out;
+}
+
 // Requirements (host-checked): IC is a power of two >= 8 dividing I; O % (32*NT) == 0; tile-local offsets fit 32 bits.
 template <int FAM, int NT, int NSH>
 __global__ __launch_bounds__(NTHR) void kan_fwd_bf16_kernel(const LayerArgs a) {
@@ -599,7 +619,11 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_bf16_kernel(const LayerArgs a) {
 //                basis_bwd of the tile parked at the end of iteration t-1;
 //                du / dx write-out one iteration after the basis_bwd that produced them.
 // =============================================================================================
-template <int FAM, int KT, bool SHARED>
+// BF (KANVIT_FLAG_BF16_MFMA, O in {16, 32, 64}): a step covers ALL dY columns of one group; the operands live in LDS as
+// bf16 in MFMA-ready images -- dY rows [row][O+8] converted while staging (A fragment = one ds_read_b128), W^T from the
+// pre-packed [O/8][KCT][8] image (B fragment = one ds_read_b128, lane = k) -- and the contraction runs on
+// v_mfma_f32_32x32x16_bf16.  Half the barriers of the fp32 schedule, no conversions in the consumer.
+template <int FAM, int KT, bool SHARED, bool BF>
 __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KCT = 32 * KT;
@@ -617,13 +641,15 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
     const int KC = IC * GP;
     const int XS = BM * ICP;
     const int nci = (a.I + IC - 1) / IC;
-    const int ncn = (a.O + BIN_NC - 1) / BIN_NC;
+    const int ncn = BF ? 1 : (a.O + BIN_NC - 1) / BIN_NC;
     const int spc = nshare * ncn;                   // steps per feature chunk
     const int T = nci * spc;
     const bool full_m = (m0 + BM <= a.M);
     const int mrem = full_m ? BM : (int)(a.M - m0);
     const bool vec_n = ((a.O & 3) == 0) && (a.O % BIN_NC == 0) && ((a.ldy & 3) == 0);   // float4 operand loads
-    constexpr int OPS = BIN_NC * AS + BIN_NC * WS;  // one operand buffer: dY_s then Wt_s
+    const int OP = a.O + 8;                         // BF: bf16 elements per dY row image (16-byte aligned, odd 16-B slot count)
+    // one operand buffer, in floats: fp32 path dY_s then Wt_s; BF path dYb[BM][OP] then Wtb[O/8][KCT][8] (bf16)
+    const int OPS = BF ? (BM * OP / 2 + (a.O / 8) * KCT * 4) : (BIN_NC * AS + BIN_NC * WS);
 
     float* x_s = smem;                              // [2][XS]  by ci parity
     float* dx_s = x_s + 2 * XS;                     // [2][XS]
@@ -642,6 +668,44 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
     // ---- producer tasks ----
     auto stage_ops = [&](int t, int ci, int p, int cn) {
         const int g = p * a.xmod + gx, n0 = cn * BIN_NC, k0 = ci * KC;
+        if constexpr (BF) {
+            unsigned short* dYb = reinterpret_cast<unsigned short*>(ops + (t & 1) * OPS);
+            unsigned short* Wtb = dYb + BM * OP;
+            const float* dyt = dyb + (long long)g * a.O;                                         // uniform
+            const int o4 = a.O >> 2, lg4 = __builtin_ctz(o4);                                    // float4 per row (4, 8 or 16)
+            const int c4 = (pt & (o4 - 1)) * 4, r0 = pt >> lg4, rpp = NPROD >> lg4;              // rows per pass
+            const int nps = a.O >> 3;                                                            // passes: BM / rpp
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q * rpp;
+                f32x4 tv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (q < nps && (full_m || r < mrem)) tv = *reinterpret_cast<const f32x4*>(dyt + r * ldy + c4);
+                v[q] = tv;
+            }
+            const int nvw = (a.O >> 3) * KCT;                                                    // 16-byte vectors of the W image
+            const unsigned short* wsrc = a.wb2 + (((long long)g * nci + ci) * nvw) * 8;          // uniform
+            u32x4 wv[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int vi = pt + q * NPROD;
+                if (vi < nvw) wv[q] = *reinterpret_cast<const u32x4*>(wsrc + (long long)vi * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < nps) {
+                    const unsigned lo = kv_pack_bf16(v[q][0], v[q][1]), hi = kv_pack_bf16(v[q][2], v[q][3]);
+                    unsigned* d2 = reinterpret_cast<unsigned*>(dYb + (r0 + q * rpp) * OP + c4);
+                    d2[0] = lo;
+                    d2[1] = hi;
+                }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int vi = pt + q * NPROD;
+                if (vi < nvw) *reinterpret_cast<u32x4*>(Wtb + (size_t)vi * 8) = wv[q];
+            }
+            return;
+        }
         float* dY_s = ops + (t & 1) * OPS;
         float* Wt_s = dY_s + BIN_NC * AS;
         const float* dyt = dyb + (long long)g * a.O + n0;                       // uniform
@@ -766,14 +830,28 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
         const bool ends = (t < T) && (SHARED ? (rem == spc - 1) : (cn == ncn - 1));
         if (consumer) {
             if (t < T && !(a.dbg & 8)) {
-                const float* ap = ops + (t & 1) * OPS + hf * AS + wave * 32 + l31;
-                const float* wp = ops + (t & 1) * OPS + BIN_NC * AS + hf * WS + l31;
-#pragma unroll 4
-                for (int s2 = 0; s2 < BIN_NC / 2; ++s2) {
-                    const float av = ap[(2 * s2) * AS];
+                if constexpr (BF) {
+                    const unsigned short* dYb = reinterpret_cast<const unsigned short*>(ops + (t & 1) * OPS);
+                    const unsigned short* ap = dYb + (wave * 32 + l31) * OP + 8 * hf;
+                    const unsigned short* bp = dYb + BM * OP + ((size_t)hf * KCT + l31) * 8;
+                    for (int ks = 0; ks < (a.O >> 4); ++ks) {
+                        const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(ap + 16 * ks);
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt)
-                        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wp[(2 * s2) * WS + kt * 32], acc[kt], 0, 0, 0);
+                        for (int kt = 0; kt < KT; ++kt) {
+                            const bf16x8_t b8 = *reinterpret_cast<const bf16x8_t*>(bp + ((size_t)(2 * ks) * KCT + kt * 32) * 8);
+                            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[kt], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    const float* ap = ops + (t & 1) * OPS + hf * AS + wave * 32 + l31;
+                    const float* wp = ops + (t & 1) * OPS + BIN_NC * AS + hf * WS + l31;
+#pragma unroll 4
+                    for (int s2 = 0; s2 < BIN_NC / 2; ++s2) {
+                        const float av = ap[(2 * s2) * AS];
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt)
+                            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wp[(2 * s2) * WS + kt * 32], acc[kt], 0, 0, 0);
+                    }
                 }
             }
         } else {
@@ -1243,31 +1321,61 @@ int dispatch_fwd(LayerArgs& a, hipStream_t st) {
 
 // ---- backward input ------------------------------------------------------------------------------
 template <int FAM>
-size_t bwd_input_lds(int ic, int gp, int G, int nshare) {
+size_t bwd_input_lds(int ic, int gp, int G, int nshare, int bf_O = 0) {
     const int kct = 32 * ((ic * gp + 31) / 32);
+    const size_t ops = bf_O ? ((size_t)BM * (bf_O + 8) / 2 + (size_t)(bf_O / 8) * kct * 4)
+                            : ((size_t)BIN_NC * AS + (size_t)BIN_NC * (kct + 1));
     return sizeof(float) * ((size_t)BM * (ic | 1) * (FAM == KV_RBF ? 8 : 4) + (FAM == KV_SINE ? (size_t)nshare * 4 * G : 0) +
-                            (size_t)kct * AS + 2 * ((size_t)BIN_NC * AS + (size_t)BIN_NC * (kct + 1)));
+                            (size_t)kct * AS + 2 * ops);
 }
 
-template <int FAM, int KT, bool SHARED>
+template <int FAM, int KT, bool SHARED, bool BF>
 int launch_bwd_input(const LayerArgs& a, hipStream_t st) {
-    const size_t lds = bwd_input_lds<FAM>(a.IC, a.GP, a.G, a.groups / a.xmod);
+    const size_t lds = bwd_input_lds<FAM>(a.IC, a.GP, a.G, a.groups / a.xmod, BF ? a.O : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(kan_bwd_input_kernel<FAM, KT, SHARED>, 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds((kan_bwd_input_kernel<FAM, KT, SHARED, BF>), 160 * 1024));
         attr_done = true;
     }
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
-    hipLaunchKernelGGL((kan_bwd_input_kernel<FAM, KT, SHARED>), grid, dim3(NTHR), lds, st, a);
+    hipLaunchKernelGGL((kan_bwd_input_kernel<FAM, KT, SHARED, BF>), grid, dim3(NTHR), lds, st, a);
     KV_LAUNCH_CHECK("kan_bwd_input_kernel");
     return 0;
 }
 
 template <int FAM, bool SHARED>
-int launch_bwd_input_kt(const LayerArgs& a, int kt, hipStream_t st) {
-    if (kt == 1) return launch_bwd_input<FAM, 1, SHARED>(a, st);
-    if (kt == 2) return launch_bwd_input<FAM, 2, SHARED>(a, st);
-    return launch_bwd_input<FAM, 3, SHARED>(a, st);
+int launch_bwd_input_kt(const LayerArgs& a, int kt, bool bf, hipStream_t st) {
+    if (bf) {
+        if (kt == 1) return launch_bwd_input<FAM, 1, SHARED, true>(a, st);
+        if (kt == 2) return launch_bwd_input<FAM, 2, SHARED, true>(a, st);
+        return launch_bwd_input<FAM, 3, SHARED, true>(a, st);
+    }
+    if (kt == 1) return launch_bwd_input<FAM, 1, SHARED, false>(a, st);
+    if (kt == 2) return launch_bwd_input<FAM, 2, SHARED, false>(a, st);
+    return launch_bwd_input<FAM, 3, SHARED, false>(a, st);
+}
+
+// chunking of the input-gradient kernel (shared by the workspace query and the launch)
+template <int FAM>
+int bwd_input_ic(int I, int gp, int G, int nshare, int bf_O) {
+    int ic = 96 / gp;
+    if (ic < 1) ic = 1;
+    if (ic > I) ic = I;
+    while (ic > 1 && bwd_input_lds<FAM>(ic, gp, G, nshare, bf_O) > 160 * 1024) --ic;
+    return bwd_input_lds<FAM>(ic, gp, G, nshare, bf_O) > 160 * 1024 ? 0 : ic;
+}
+
+bool bwd_input_bf16_ok(const kanvit_layer_desc* d) {
+    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64) && (d->ldy % 4 == 0) && !getenv("KANVIT_NO_BF16");
+}
+
+template <int FAM>
+size_t bwd_input_ws(const kanvit_layer_desc* d) {
+    const int gp = gp_of(d), nshare = d->groups / d->x_group_mod;
+    const int ic = bwd_input_ic<FAM>(d->I, gp, d->G, nshare, d->O);
+    if (!ic) return 0;
+    const int kct = 32 * ((ic * gp + 31) / 32), nci = (d->I + ic - 1) / ic;
+    return (size_t)d->groups * nci * (d->O / 8) * kct * 16;
 }
 
 template <int FAM>
@@ -1275,17 +1383,25 @@ int dispatch_bwd_input(LayerArgs& a, hipStream_t st) {
     if ((long long)BM * a.ldx >= (1LL << 30) || (long long)BM * a.ldy >= (1LL << 30) || (long long)BM * a.ldu >= (1LL << 30) ||
         (long long)a.K * a.O >= (1LL << 30))
         return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: row strides / weight slab too large for 32-bit tile offsets");
-    int ic = 96 / a.GP;
-    if (ic < 1) ic = 1;
-    if (ic > a.I) ic = a.I;
     const int nshare = a.groups / a.xmod;
-    while (ic > 1 && bwd_input_lds<FAM>(ic, a.GP, a.G, nshare) > 160 * 1024) --ic;
-    if (bwd_input_lds<FAM>(ic, a.GP, a.G, nshare) > 160 * 1024)
-        return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: tile does not fit the LDS");
+    bool bf = a.wb2 != nullptr;                         // set by the entry point when the bf16 path applies
+    int ic = bwd_input_ic<FAM>(a.I, a.GP, a.G, nshare, bf ? a.O : 0);
+    if (!ic && bf) {
+        bf = false;
+        ic = bwd_input_ic<FAM>(a.I, a.GP, a.G, nshare, 0);
+    }
+    if (!ic) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: tile does not fit the LDS");
     a.IC = ic;
     const int kt = (ic * a.GP + 31) / 32;
-    if (kv_shared_basis<FAM>() && nshare > 1) return launch_bwd_input_kt<FAM, true>(a, kt, st);
-    return launch_bwd_input_kt<FAM, false>(a, kt, st);
+    if (bf) {
+        const int kct = 32 * kt, nci = (a.I + ic - 1) / ic;
+        const long long total = (long long)a.groups * nci * (a.O / 8) * kct;
+        hipLaunchKernelGGL(kan_pack_w_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w,
+                           const_cast<unsigned short*>(a.wb2), a.K, a.O, ic * a.GP, kct, nci, total);
+        KV_LAUNCH_CHECK("kan_pack_w_bwd_kernel");
+    }
+    if (kv_shared_basis<FAM>() && nshare > 1) return launch_bwd_input_kt<FAM, true>(a, kt, bf, st);
+    return launch_bwd_input_kt<FAM, false>(a, kt, bf, st);
 }
 
 // ---- backward weight -----------------------------------------------------------------------------
@@ -1425,15 +1541,21 @@ int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d) {
 }
 
 size_t kanvit_layer_bwd_input_workspace(const kanvit_layer_desc* d) {
-    (void)d;
-    return 0;      // the bf16 input-gradient kernel is not built yet: the exact fp32 kernel runs for every flag
+    if (!d || gp_of(d) < 1 || d->groups < 1 || d->x_group_mod < 1 || d->I < 1 || d->O < 1 || !bwd_input_bf16_ok(d)) return 0;
+    switch (d->family) {
+        case KANVIT_LINEAR: return bwd_input_ws<KV_LINEAR>(d);
+        case KANVIT_CHEBY: return bwd_input_ws<KV_CHEBY>(d);
+        case KANVIT_BSPLINE: return bwd_input_ws<KV_BSPLINE>(d);
+        case KANVIT_RBF: return bwd_input_ws<KV_RBF>(d);
+        case KANVIT_SINE: return bwd_input_ws<KV_SINE>(d);
+        case KANVIT_FOURIER: return bwd_input_ws<KV_FOURIER>(d);
+        default: return 0;
+    }
 }
 
 int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const float* u, const float* w,
                            const float* bparams, const float* dy, float* dx, float* du, float* dparam, void* workspace,
                            size_t workspace_bytes, void* stream) {
-    (void)workspace;
-    (void)workspace_bytes;
     if (int rc = validate(d, "kanvit_layer_bwd_input")) return rc;
     if (d->M == 0) return 0;
     if (!x || !w || !dy || !dx) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: null x/w/dy/dx");
@@ -1453,6 +1575,16 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
     a.dx = dx;
     a.du = du;
     a.dparam = dparam;
+    a.wb2 = nullptr;
+    if (bwd_input_bf16_ok(d) && (((uintptr_t)dy & 15) == 0)) {
+        const size_t need = kanvit_layer_bwd_input_workspace(d);
+        if (need) {
+            if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))
+                return kv_fail(KANVIT_ENOMEM, "kanvit_layer_bwd_input: workspace %zu bytes < required %zu (or not 16-byte aligned)",
+                               workspace_bytes, need);
+            a.wb2 = (const unsigned short*)workspace;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
 #define KV_CALL(F) dispatch_bwd_input<F>(a, st)
     KV_FAMILY_SWITCH(d->family, KV_CALL)

@@ -182,7 +182,8 @@ class _KanLayerFn(torch.autograd.Function):
                     dpart = torch.empty(tiles, cfg.groups, cfg.G, device=x.device, dtype=torch.float32)
                 nb_in = int(L.kanvit_layer_bwd_input_workspace(C.byref(d)))
                 ws_in = _workspace(nb_in, x.device) if nb_in else None
-                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_input", *_layer_cost(cfg, M, "bwd_input")):
+                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_input" + ("_bf16" if nb_in else ""),
+                            *_layer_cost(cfg, M, "bwd_input")):
                     check(L.kanvit_layer_bwd_input(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(dy),
                                                    _ptr(dx), _ptr(du_buf), _ptr(dpart), _ptr(ws_in), C.c_size_t(nb_in),
                                                    _stream()), "kanvit_layer_bwd_input")

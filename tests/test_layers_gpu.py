@@ -163,21 +163,23 @@ def test_bf16_mfma_forward_close_to_fp32(fam):
     assert 0 < err < 2e-2, (fam, err)          # > 0: the bf16 kernel really ran
 
 
-@pytest.mark.parametrize("fam", ["cheby", "efficientkan", "sine"])
-def test_bf16_mfma_weight_gradient_close_to_fp32(fam):
+@pytest.mark.parametrize("fam", ["vanilla", "cheby", "efficientkan", "fast", "sine"])
+@pytest.mark.parametrize("dh", [64, 32])
+def test_bf16_mfma_gradients_close_to_fp32(fam, dh):
     from attention import MSA
     from kanvit import grouped
     torch.manual_seed(4)
-    msa = MSA(256, 4, type=fam).to(DEV)
-    x = torch.randn(4 * 197, 256, device=DEV)
-    w = torch.randn(4 * 197, 768, device=DEV)
+    msa = MSA(4 * dh, 4, type=fam).to(DEV)
+    x = torch.randn(4 * 197 + 5, 4 * dh, device=DEV, requires_grad=True)
+    w = torch.randn(4 * 197 + 5, 12 * dh, device=DEV)
 
     def grads(amp):
         msa.zero_grad()
+        x.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             y = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
         (y * w).sum().backward()
-        return [p.grad.clone() for p in msa.parameters() if p.grad is not None]
+        return [x.grad.clone()] + [p.grad.clone() for p in msa.parameters() if p.grad is not None]
 
     for a, b in zip(grads(True), grads(False)):
         if float(b.abs().max()) > 1e-3:
