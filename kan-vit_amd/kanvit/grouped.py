@@ -50,12 +50,16 @@ def run_qkv(q_layers: Sequence, k_layers: Sequence, v_layers: Sequence, x2d: tor
     layer acts row-wise."""
     H = len(q_layers)
     layers = list(q_layers) + list(k_layers) + list(v_layers)
-    cfg0, _ = _cfg_pack(layers[0])
-    packs = [_cfg_pack(m)[1] for m in layers]
+    cfg0 = linear_cfg(layers[0]) if isinstance(layers[0], torch.nn.Linear) else layers[0].kan_cfg()
     cfg = replace(cfg0, groups=3 * H, x_group_mod=H)
-    w = torch.stack([p[0] for p in packs], dim=0)
-    bp = None if packs[0][1] is None else torch.stack([p[1] for p in packs], dim=0)
-    bias = None if packs[0][2] is None else torch.stack([p[2] for p in packs], dim=0)
+    # Pack ALL 3*H layers with one stack + one layout transform (a handful of launches) instead of a
+    # permute-copy per head (3*H launches forward and again backward: 880 tiny kernels per ViT-B step).
+    if isinstance(layers[0], torch.nn.Linear):
+        w = torch.stack([m.weight for m in layers]).permute(0, 2, 1)
+        bp = None
+        bias = None if layers[0].bias is None else torch.stack([m.bias for m in layers])
+    else:
+        w, bp, bias = type(layers[0]).kan_pack_grouped(layers)
     u = None
     if hasattr(layers[0], "kan_u_grouped"):
         u = type(layers[0]).kan_u_grouped(layers, x2d, H)

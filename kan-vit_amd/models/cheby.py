@@ -33,5 +33,11 @@ class ChebyKANLayer(nn.Module):
         w = self.cheby_coeffs.permute(0, 2, 1).reshape(self.inputdim * (self.degree + 1), self.outdim)
         return w, None, None
 
+    @staticmethod
+    def kan_pack_grouped(layers):
+        c = torch.stack([m.cheby_coeffs for m in layers])                    # [g, I, O, D+1]
+        g, i, o, d1 = c.shape
+        return c.permute(0, 1, 3, 2).reshape(g, i * d1, o), None, None
+
     def forward(self, x):
         return grouped.run_single(self, x.reshape(-1, self.inputdim))

@@ -71,6 +71,19 @@ class FastKANLayer(nn.Module):
             bias = self.base_linear.bias
         return w.reshape(-1, o), self.rbf.grid.detach(), bias
 
+    @staticmethod
+    def kan_pack_grouped(layers):
+        l0 = layers[0]
+        i, gr, o = l0.input_dim, l0.num_grids, l0.output_dim
+        g = len(layers)
+        w = torch.stack([m.spline_linear.weight for m in layers]).view(g, o, i, gr).permute(0, 2, 3, 1)   # [g, I, G, O]
+        bias = None
+        if l0.use_base_update:
+            bw = torch.stack([m.base_linear.weight for m in layers]).permute(0, 2, 1).unsqueeze(2)       # [g, I, 1, O]
+            w = torch.cat([w, bw], dim=2)
+            bias = torch.stack([m.base_linear.bias for m in layers])
+        return w.reshape(g, -1, o), torch.stack([m.rbf.grid.detach() for m in layers]), bias
+
     def kan_u(self, x2d):
         return self.layernorm(x2d) if getattr(self, "_use_ln", True) else None
 
