@@ -41,6 +41,14 @@ extern "C" {
                                     I/O); used for the bf16 configurations, never for the fp32 parity path.  Shapes
                                     the bf16 kernels do not cover silently use the exact fp32 kernels.               */
 
+#define KANVIT_FLAG_UNIFORM_KNOTS 2 /* BSPLINE, spline_order 3: every knot row is g0 + j*h (the layout the reference builds
+                                    at models/effkan.py:44-53 and never changes) -> closed-form cubic evaluation of
+                                    the 4 non-zero bases instead of the Cox-de Boor recursion.  g0, h are read from
+                                    the first two knots of each group.                                              */
+#define KANVIT_FLAG_SHARED_BPARAMS 4 /* groups that read the same x columns (q, k, v of a head) also have identical
+                                    basis parameters, so one basis tile may serve all of them (as for the
+                                    parameter-free families).  Honoured for BSPLINE.                                */
+
 /* basis families: phi_g(x) generated on the fly, never stored in HBM */
 #define KANVIT_LINEAR 0   /* phi = x                               nn.Linear in attention.py:136-142           */
 #define KANVIT_CHEBY 1    /* T_g(tanh x), g = 0..degree            models/cheby.py:36-48                       */

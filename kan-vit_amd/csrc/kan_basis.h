@@ -30,6 +30,7 @@ struct BasisArgs {
     int has_base;      // BSPLINE / RBF
     float inv_h;       // RBF
     const float* bp;   // this group's parameter table
+    int uniform;       // BSPLINE: KANVIT_FLAG_UNIFORM_KNOTS (closed-form cubic)
 };
 
 // tanh(x) = 1 - 2/(exp(2x)+1): v_exp_f32 + v_rcp_f32, absolute error ~2e-7 over the whole range
@@ -104,6 +105,33 @@ __device__ __noinline__ void kv_bspline_rt(const float* __restrict__ kn, int nk,
     }
 }
 
+// Uniform cubic B-splines (knots g0 + j*h): for x in knot interval j0 the four non-zero bases are j0-3 .. j0 with
+//   (1-u)^3/6, (3u^3-6u^2+4)/6, (-3u^3+3u^2+3u+1)/6, u^3/6,  u = (x-g0)/h - j0   (same values as Cox-de Boor, e.g. x = 0 on
+// the reference grid gives [.., 1/48, 23/48, 23/48, 1/48, ..]); outside [g0, g0 + (nk-1)h) everything is zero, which is the
+// half-open order-0 indicator of models/effkan.py:115.
+__device__ __forceinline__ bool kv_bspline_uniform(const float* __restrict__ kn, int nk, float xv, int& j0, float (&bv)[4],
+                                                   float (&dv)[4], bool want_der) {
+    const float g0 = kn[0], h = (kn[nk - 1] - kn[0]) / (float)(nk - 1);
+    const float ih = __frcp_rn(h);
+    const float t = (xv - g0) * ih;
+    const float fl = floorf(t);
+    j0 = (int)fl;
+    if (!(t >= 0.0f) || j0 >= nk - 1) return false;
+    const float u = t - fl, u2 = u * u, u3 = u2 * u, om = 1.0f - u;
+    const float s6 = 1.0f / 6.0f;
+    bv[0] = om * om * om * s6;
+    bv[1] = (3.0f * u3 - 6.0f * u2 + 4.0f) * s6;
+    bv[2] = (-3.0f * u3 + 3.0f * u2 + 3.0f * u + 1.0f) * s6;
+    bv[3] = u3 * s6;
+    if (want_der) {
+        dv[0] = -0.5f * om * om * ih;
+        dv[1] = (1.5f * u2 - 2.0f * u) * ih;
+        dv[2] = (-1.5f * u2 + u + 0.5f) * ih;
+        dv[3] = 0.5f * u2 * ih;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: write GP values for feature i (value xv; RBF spline path uses uv) to dst[j*stride]
 // ---------------------------------------------------------------------------------------------
@@ -125,7 +153,19 @@ __device__ __forceinline__ void basis_fwd(const BasisArgs& b, float xv, float uv
         }
     } else if constexpr (FAM == KV_BSPLINE) {
         const float* kn = b.bp + (long long)i * b.nk;
-        if (b.nk == 12 && b.order == 3) {          // grid_size 5, spline_order 3: every call site of the reference
+        if (b.uniform) {                           // order 3, uniform knots (host-checked): 4 non-zero bases
+            int j0;
+            float bv[4], dv[4];
+            const bool in = kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, false);
+            for (int j = 0; j < b.G; ++j) dst[j * stride] = 0.0f;
+            if (in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = j0 - 3 + e;
+                    if (idx >= 0 && idx < b.G) dst[idx * stride] = bv[e];
+                }
+            }
+        } else if (b.nk == 12 && b.order == 3) {   // grid_size 5, spline_order 3: every call site of the reference
             float val[8];
             kv_bspline_fixed<12, 3, false>(kn, xv, val, nullptr);
 #pragma unroll
@@ -193,7 +233,17 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
     } else if constexpr (FAM == KV_BSPLINE) {
         const float* kn = b.bp + (long long)i * b.nk;
         float acc = 0.0f;
-        if (b.nk == 12 && b.order == 3) {
+        if (b.uniform) {
+            int j0;
+            float bv[4], dv[4];
+            if (kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, true)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = j0 - 3 + e;
+                    if (idx >= 0 && idx < b.G) acc += dA[idx * stride] * dv[e];
+                }
+            }
+        } else if (b.nk == 12 && b.order == 3) {
             float val[8], der[8];
             kv_bspline_fixed<12, 3, true>(kn, xv, val, der);
 #pragma unroll

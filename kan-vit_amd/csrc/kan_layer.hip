@@ -53,6 +53,7 @@ struct LayerArgs {
     long long M, ldx, ldu, ldy, bp_stride, rows_per_split;
     int I, O, groups, xmod, G, GP, order, nk, has_base, K, IC, msplit, nchunks_n;
     float rbf_inv_h;
+    int flags;
     int dbg;   // KANVIT_DBG ablation mask (timing experiments only; results are wrong when non-zero)
 };
 
@@ -65,6 +66,7 @@ __device__ __forceinline__ BasisArgs make_basis(const LayerArgs& a, int g) {
     b.has_base = a.has_base;
     b.inv_h = a.rbf_inv_h;
     b.bp = a.bp ? a.bp + (long long)g * a.bp_stride : nullptr;
+    b.uniform = (a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3;
     return b;
 }
 
@@ -1179,6 +1181,7 @@ LayerArgs base_args(const kanvit_layer_desc* d) {
     a.has_base = d->has_base;
     a.K = d->I * a.GP;
     a.rbf_inv_h = d->rbf_inv_h;
+    a.flags = d->flags;
     const char* dbg = getenv("KANVIT_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
     return a;
@@ -1187,8 +1190,15 @@ LayerArgs base_args(const kanvit_layer_desc* d) {
 int needs_bparams(int family) { return family == KANVIT_BSPLINE || family == KANVIT_RBF || family == KANVIT_SINE; }
 
 // ---- forward -----------------------------------------------------------------------------------
+// families that get shared-basis (NSH = 3 / SHARED) kernel instantiations ...
 template <int FAM>
-constexpr bool kv_shared_basis() { return FAM == KV_LINEAR || FAM == KV_CHEBY || FAM == KV_FOURIER; }
+constexpr bool kv_shared_basis() { return FAM == KV_LINEAR || FAM == KV_CHEBY || FAM == KV_FOURIER || FAM == KV_BSPLINE; }
+// ... and whether a given launch may use them: parameter-free families always, BSPLINE when the caller vouches that the
+// groups sharing x also share the knot table (KANVIT_FLAG_SHARED_BPARAMS)
+inline bool kv_share_ok(int family, int flags) {
+    return family == KANVIT_LINEAR || family == KANVIT_CHEBY || family == KANVIT_FOURIER ||
+           (family == KANVIT_BSPLINE && (flags & KANVIT_FLAG_SHARED_BPARAMS));
+}
 
 template <int FAM>
 size_t fwd_lds(int ic, int gp, int nt, int nsh) {
@@ -1231,7 +1241,7 @@ FwdBf16Plan plan_fwd_bf16(const kanvit_layer_desc* d) {
     const int gp = gp_of(d);
     p.nt = d->O <= 32 ? 1 : (d->O <= 64 ? 2 : 4);
     const int nshare = d->groups / d->x_group_mod;
-    const bool shared_fam = d->family == KANVIT_LINEAR || d->family == KANVIT_CHEBY || d->family == KANVIT_FOURIER;
+    const bool shared_fam = kv_share_ok(d->family, d->flags);
     p.nsh = (shared_fam && nshare == 3 && p.nt <= 2) ? 3 : 1;
     if (getenv("KANVIT_BF16_NSH")) p.nsh = atoi(getenv("KANVIT_BF16_NSH")) == 3 && p.nsh == 3 ? 3 : 1;   // tuning knob
     const int icmax = getenv("KANVIT_BF16_IC") ? atoi(getenv("KANVIT_BF16_IC")) : 64;                    // tuning knob
@@ -1292,7 +1302,7 @@ template <int FAM>
 int dispatch_fwd(LayerArgs& a, hipStream_t st) {
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     const int nshare = a.groups / a.xmod;
-    const bool share3 = kv_shared_basis<FAM>() && nshare == 3 && nt <= 2;
+    const bool share3 = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare == 3 && nt <= 2;
     const int nsh = share3 ? 3 : 1;
     // largest feature chunk whose two operand buffers fit the 160 KiB LDS (cap 80 columns)
     int ic = 80 / a.GP;
@@ -1400,7 +1410,9 @@ int dispatch_bwd_input(LayerArgs& a, hipStream_t st) {
                            const_cast<unsigned short*>(a.wb2), a.K, a.O, ic * a.GP, kct, nci, total);
         KV_LAUNCH_CHECK("kan_pack_w_bwd_kernel");
     }
-    if (kv_shared_basis<FAM>() && nshare > 1) return launch_bwd_input_kt<FAM, true>(a, kt, bf, st);
+    if constexpr (kv_shared_basis<FAM>()) {
+        if (kv_share_ok(FAM, a.flags) && nshare > 1) return launch_bwd_input_kt<FAM, true>(a, kt, bf, st);
+    }
     return launch_bwd_input_kt<FAM, false>(a, kt, bf, st);
 }
 
@@ -1414,7 +1426,7 @@ BwPlan plan_bwd_weight(const kanvit_layer_desc* d) {
     BwPlan p;
     const int gp = gp_of(d);
     const int nshare = d->groups / d->x_group_mod;
-    const bool shared_fam = d->family == KANVIT_LINEAR || d->family == KANVIT_CHEBY || d->family == KANVIT_FOURIER;
+    const bool shared_fam = kv_share_ok(d->family, d->flags);
     p.nsh = (shared_fam && nshare == 3) ? 3 : 1;
     // NSH = 3: 6 column tiles per k tile, at most 8 tiles per wave -> KT <= 5 (KC <= 160)
     const int kcmax = p.nsh == 3 ? 160 : BW_KC_MAX;

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(HERE, "libkanvit.so")
 
 LINEAR, CHEBY, BSPLINE, RBF, SINE, FOURIER = range(6)
 FLAG_BF16_MFMA = 1
+FLAG_UNIFORM_KNOTS = 2
+FLAG_SHARED_BPARAMS = 4
 FAMILY_NAMES = ["linear", "cheby", "bspline", "rbf", "sine", "fourier"]
 
 

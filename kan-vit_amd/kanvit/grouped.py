@@ -50,7 +50,12 @@ def run_qkv(q_layers: Sequence, k_layers: Sequence, v_layers: Sequence, x2d: tor
     layer acts row-wise."""
     H = len(q_layers)
     layers = list(q_layers) + list(k_layers) + list(v_layers)
-    cfg0 = linear_cfg(layers[0]) if isinstance(layers[0], torch.nn.Linear) else layers[0].kan_cfg()
+    if isinstance(layers[0], torch.nn.Linear):
+        cfg0 = linear_cfg(layers[0])
+    elif hasattr(type(layers[0]), "kan_pack_grouped") and "layers" in layers[0].kan_cfg.__code__.co_varnames:
+        cfg0 = layers[0].kan_cfg(layers)          # family whose flags depend on all the layers (efficient-KAN knot tables)
+    else:
+        cfg0 = layers[0].kan_cfg()
     cfg = replace(cfg0, groups=3 * H, x_group_mod=H)
     # Pack ALL 3*H layers with one stack + one layout transform (a handful of launches) instead of a
     # permute-copy per head (3*H launches forward and again backward: 880 tiny kernels per ViT-B step).

@@ -9,7 +9,30 @@ import math
 import torch
 import torch.nn.functional as F
 
-from kanvit import grouped, ops
+from kanvit import _lib, grouped, ops
+
+
+_GRID_FACTS = {}      # (ids, versions, data_ptrs of the knot buffers) -> (uniform, all_equal)
+
+
+def _grid_facts(layers):
+    """Are the knot buffers uniform (g0 + j*h, the only layout the reference ever builds, models/effkan.py:44-53) and
+    identical across `layers`?  Checked once per set of buffers (needs a host sync) and cached on their version
+    counters, so an in-place change of any grid is noticed."""
+    key = tuple((id(m), m.grid._version, m.grid.data_ptr()) for m in layers)
+    hit = _GRID_FACTS.get(key)
+    if hit is None:
+        g0 = layers[0].grid
+        row = g0[0].double()
+        step = (row[-1] - row[0]) / (row.numel() - 1)              # the kernel derives h the same way
+        ideal = row[0] + step * torch.arange(row.numel(), device=row.device, dtype=torch.float64)
+        tol = 2e-6 * (float(row.abs().max()) + 1.0)                # a few float32 ulps of the knot range
+        uniform = bool(float(step) > 0 and float((row - ideal).abs().max()) <= tol and bool((g0 == g0[0:1]).all()))
+        equal = all(m.grid.shape == g0.shape and bool((m.grid == g0).all()) for m in layers[1:])
+        if len(_GRID_FACTS) > 256:
+            _GRID_FACTS.clear()
+        hit = _GRID_FACTS[key] = (uniform and layers[0].spline_order == 3, equal)
+    return hit
 
 
 class KANLinear(torch.nn.Module):
@@ -89,9 +112,11 @@ class KANLinear(torch.nn.Module):
         return self.spline_weight
 
     # ---- fused-kernel protocol ----
-    def kan_cfg(self):
+    def kan_cfg(self, layers=None):
+        uniform, equal = _grid_facts(layers if layers is not None else [self])
+        flags = (_lib.FLAG_UNIFORM_KNOTS if uniform and equal else 0) | (_lib.FLAG_SHARED_BPARAMS if equal and layers is not None else 0)
         return ops.LayerCfg(family=ops.BSPLINE, I=self.in_features, O=self.out_features,
-                            G=self.grid_size + self.spline_order, spline_order=self.spline_order, has_base=1)
+                            G=self.grid_size + self.spline_order, spline_order=self.spline_order, has_base=1, flags=flags)
 
     def kan_pack(self):
         # [O, I, nb] (scaled) and base [O, I] -> [I, nb+1, O] -> [I*(nb+1), O]; base column last

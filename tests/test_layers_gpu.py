@@ -184,3 +184,28 @@ def test_bf16_mfma_gradients_close_to_fp32(fam, dh):
     for a, b in zip(grads(True), grads(False)):
         if float(b.abs().max()) > 1e-3:
             assert float((a - b).abs().max()) / float(b.abs().max()) < 3e-2, fam
+
+
+def test_bspline_non_uniform_or_differing_grids_take_the_general_path():
+    """The closed-form / shared-basis shortcuts are only taken when the knot buffers allow it."""
+    from attention import MSA
+    from kanvit import grouped
+    from models.effkan import _grid_facts
+    torch.manual_seed(6)
+    msa = MSA(128, 2, type="efficientkan").to(DEV)
+    layers = list(msa.q_mappings) + list(msa.k_mappings) + list(msa.v_mappings)
+    assert _grid_facts(layers) == (True, True)
+    x = torch.randn(300, 128, device=DEV)
+    ref = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x).cpu()
+    with torch.no_grad():
+        msa.k_mappings[1].grid[:, 5] += 0.05           # one layer gets a non-uniform knot vector
+    assert _grid_facts(layers) == (True, False)        # (layer 0 still uniform, but not all equal)
+    got = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+    sd = {k: v.detach().cpu().double() if v.is_floating_point() else v.cpu() for k, v in msa.state_dict().items()}
+    want = []
+    for name in ("q", "k", "v"):
+        for hh in range(2):
+            want.append(ko.layer_forward(sd, f"{name}_mappings.{hh}.", x.cpu().double()[:, hh * 64:(hh + 1) * 64]))
+    want = torch.cat(want, dim=1)
+    assert max_err(got.cpu(), want) < FWD_TOL * max(1.0, float(want.abs().max()))
+    assert max_err(got.cpu()[:, :64 * 3], ref[:, :64 * 3]) < 1e-6        # untouched layers unchanged
