@@ -290,3 +290,76 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
         dx = acc;
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Generator form of the same bases: init() once per (row, feature), then next(j) for j = 0 .. GP-1 in order.  Used by
+// the register-operand forward kernel, where every lane feeds its MFMA A operand directly (no LDS basis tile), so the
+// values must come out one at a time without runtime-indexed register arrays.
+// ---------------------------------------------------------------------------------------------
+template <int FAM>
+struct BasisGen {
+    float x, u, t, p0, p1, c1, s1, ck, sk;
+    float bv[4];
+    int j0, G, i;
+    bool in;
+    const float* bp;
+    float inv_h;
+    int has_base;
+
+    __device__ __forceinline__ void init(const BasisArgs& b, float xv, float uv, int feat) {
+        x = xv;
+        u = uv;
+        G = b.G;
+        i = feat;
+        bp = b.bp;
+        inv_h = b.inv_h;
+        has_base = b.has_base;
+        if constexpr (FAM == KV_CHEBY) {
+            t = kv_tanh(xv);
+            p0 = 1.0f;
+            p1 = t;
+        } else if constexpr (FAM == KV_BSPLINE) {
+            float dv[4];
+            in = kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, false);     // uniform knots only (host-checked)
+        } else if constexpr (FAM == KV_FOURIER) {
+            sincosf(xv, &s1, &c1);
+            ck = c1;
+            sk = s1;
+        }
+    }
+    __device__ __forceinline__ float next(int j) {
+        if constexpr (FAM == KV_LINEAR) {
+            return x;
+        } else if constexpr (FAM == KV_CHEBY) {
+            if (j == 0) return 1.0f;
+            if (j == 1) return t;
+            const float p2 = 2.0f * t * p1 - p0;
+            p0 = p1;
+            p1 = p2;
+            return p2;
+        } else if constexpr (FAM == KV_BSPLINE) {
+            if (j >= G) return kv_silu(x);
+            const int e = j - (j0 - 3);
+            const float v = e == 0 ? bv[0] : (e == 1 ? bv[1] : (e == 2 ? bv[2] : bv[3]));
+            return (in && e >= 0 && e < 4) ? v : 0.0f;
+        } else if constexpr (FAM == KV_RBF) {
+            if (j >= G) return kv_silu(x);
+            const float d = (u - bp[j]) * inv_h;
+            return __expf(-d * d);
+        } else if constexpr (FAM == KV_SINE) {
+            return sinf(__fadd_rn(__fmul_rn(x, bp[j]), bp[G + (long long)i * G + j]));
+        } else {   // FOURIER: cos(k x) for j < G, then sin(k x)
+            if (j == 0) return c1;
+            if (j == G) {
+                ck = c1;
+                sk = s1;
+                return s1;
+            }
+            const float cn = ck * c1 - sk * s1;
+            sk = sk * c1 + ck * s1;
+            ck = cn;
+            return j < G ? ck : sk;
+        }
+    }
+};

@@ -367,6 +367,161 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_kernel(const LayerArgs a) {
 }
 
 // =============================================================================================
+// forward, register-operand form (fp32 exact).  Because the fp32 MFMA and VALU work serialise on a SIMD no matter which
+// wave issues them (section header above), nothing is gained by evaluating the basis in other waves -- and the LDS basis
+// tile, its barriers and the producer waves are pure overhead.  Here every lane generates its own MFMA A operand:
+//   the K index is permuted so that lane half hf owns whole features: k-step s of a chunk <-> (feature j = s / GP of the
+//   half's ICH features, basis index g = s % GP); A[row = lane&31][k = hf] = phi_g(x[row][i0 + hf*ICH + j]) comes straight
+//   from a BasisGen in registers, and the W chunk is staged with the same permutation (row (s, hf) <- k = feature*GP + g).
+// 256 threads = 4 waves x 32 rows; LDS holds only two W chunk buffers (float4 global loads prefetched into registers one
+// chunk ahead); x is read by each lane directly (ICH consecutive floats of its row per chunk); one barrier per chunk.
+// Epilogue: each wave transposes its 32x32 tiles through a private LDS patch and writes float4 row segments.
+// Requirements (host-checked): O % (32*NT) == 0, I % IC == 0, IC in {8, 4, 2}, 16-byte aligned rows when IC == 8.
+// =============================================================================================
+template <int FAM, int NT, int NSH, int ICH>
+__global__ __launch_bounds__(256) void kan_fwd_reg_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 32 * NT;
+    constexpr int WROW = NSH * BN;
+    constexpr int V4 = BN / 4;
+    constexpr int IC = 2 * ICH;
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr int TS = 36;                        // staging patch row stride (floats): 16-byte aligned, conflict free
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int ntn = a.O / BN;
+    const int gs = blockIdx.x / ntn;
+    const int n0 = (blockIdx.x - gs * ntn) * BN;
+    const int nsets = a.groups / NSH;
+    const long long m0 = (long long)blockIdx.y * BM;
+    const int GP = a.GP, KC = IC * GP;            // k rows per chunk (even)
+    const int nch = a.I / IC;
+    const int WSZ = KC * WROW;
+    const int mrem = (m0 + BM <= a.M) ? BM : (int)(a.M - m0);
+    float* W_s = smem;                            // [2][KC][WROW], row (2s + hf)
+
+    const BasisArgs b = make_basis(a, gs);
+    const int xcol = (NSH == 1 ? gs % a.xmod : gs) * a.I;
+    const int row = wave * 32 + l31;
+    const bool row_ok = row < mrem;
+    const float* xrow = a.x + (m0 + (row_ok ? row : 0)) * a.ldx + xcol + hf * ICH;
+    const float* urow = (RBF && a.u) ? a.u + (m0 + (row_ok ? row : 0)) * a.ldu + (long long)gs * a.I + hf * ICH : xrow;
+
+    // W staging: thread -> (LDS row lr = tid / V4 (+ 256/V4 per pass), 4 columns wc); LDS row (s, h) <- global k
+    const int wc = (tid & (V4 - 1)) * 4, wr0 = tid / V4;
+    constexpr int WRS = 256 / V4;
+    constexpr int WQ = (NSH == 3) ? 4 : 8;        // passes held in registers (host guarantees ceil(KC / WRS) <= WQ)
+    f32x4 wreg[NSH][WQ];
+    int koff[WQ];                                 // natural k offset (times O) of the LDS rows this thread stages, or -1
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int lr = wr0 + q * WRS;             // LDS row = 2*s + h
+        const int s_ = lr >> 1, h_ = lr & 1;
+        const int j_ = s_ / GP, g_ = s_ - j_ * GP;
+        koff[q] = (lr < KC) ? ((h_ * ICH + j_) * GP + g_) * a.O : -1;
+    }
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int p = 0; p < NSH; ++p) {
+            const int g = (NSH == 1) ? gs : p * nsets + gs;
+            const float* src = a.w + ((long long)g * a.K + (long long)c * KC) * a.O + n0 + wc;      // chunk base (natural k order)
+#pragma unroll
+            for (int q = 0; q < WQ; ++q)
+                if (koff[q] >= 0) wreg[p][q] = *reinterpret_cast<const f32x4*>(src + koff[q]);
+        }
+    };
+    auto store_w = [&](int buf) {
+        float* dst = W_s + buf * WSZ + wc;
+#pragma unroll
+        for (int p = 0; p < NSH; ++p)
+#pragma unroll
+            for (int q = 0; q < WQ; ++q)
+                if (koff[q] >= 0) *reinterpret_cast<f32x4*>(dst + (wr0 + q * WRS) * WROW + p * BN) = wreg[p][q];
+    };
+
+    f32x16 acc[NSH * NT];
+#pragma unroll
+    for (int t = 0; t < NSH * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    float xv[ICH], uv[ICH];
+    auto load_x = [&](int c) {
+        if constexpr (ICH == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + c * IC);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = v[e];
+            if (RBF) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(urow + c * IC);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) uv[e] = w4[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < ICH; ++e) {
+                xv[e] = xrow[c * IC + e];
+                if (RBF) uv[e] = urow[c * IC + e];
+            }
+        }
+    };
+
+    load_w(0);
+    load_x(0);
+    store_w(0);
+    __syncthreads();
+
+    for (int c = 0; c < nch; ++c) {
+        float xc[ICH], uc[ICH];
+#pragma unroll
+        for (int e = 0; e < ICH; ++e) {
+            xc[e] = xv[e];
+            uc[e] = RBF ? uv[e] : 0.0f;
+        }
+        if (c + 1 < nch) {                        // prefetch the next chunk; lands while this chunk's MFMAs run
+            load_w(c + 1);
+            load_x(c + 1);
+        }
+        const float* wp = W_s + (c & 1) * WSZ + hf * WROW + l31;
+#pragma unroll
+        for (int j = 0; j < ICH; ++j) {
+            BasisGen<FAM> gen;
+            gen.init(b, xc[j], uc[j], c * IC + hf * ICH + j);
+            const float* wj = wp + (2 * j * GP) * WROW;
+            for (int g = 0; g < GP; ++g) {
+                const float av = gen.next(g);
+#pragma unroll
+                for (int t = 0; t < NSH * NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wj[(2 * g) * WROW + t * 32], acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nch) store_w((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: per-wave transpose of each 32x32 tile through a private LDS patch, float4 row-segment stores
+    float* T_w = smem + wave * 32 * TS;           // W_s is dead after the last barrier (host sizes LDS >= 4*32*TS floats)
+    const int er = lane >> 3, ec = (lane & 7) * 4;    // 8 lanes cover one 32-float row segment; 8 rows per pass
+#pragma unroll
+    for (int t = 0; t < NSH * NT; ++t) {
+        const int p = t / NT, nt = t - p * NT;
+        const int g = (NSH == 1) ? gs : p * nsets + gs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T_w[kv_acc_row(r, hf) * TS + l31] = acc[t][r];
+        f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)g * a.O + n0 + nt * 32 + ec);
+        float* yt = a.y + (m0 + wave * 32) * a.ldy + (long long)g * a.O + n0 + nt * 32 + ec;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = er + q * 8;
+            if (wave * 32 + rr < mrem) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(T_w + rr * TS + ec);
+                v += bv;
+                *reinterpret_cast<f32x4*>(yt + (long long)rr * a.ldy) = v;
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // bf16 matrix-core variants (KANVIT_FLAG_BF16_MFMA; the bf16 configurations of BASELINE.json).
 // Same producer/consumer pipeline and the same fp32 LDS basis tile as above; what changes is the
 // contraction: the consumer gathers 8 consecutive k of its row from the K-major fp32 tile
@@ -1298,8 +1453,69 @@ int dispatch_fwd_bf16(LayerArgs& a, const FwdBf16Plan& p, void* ws, hipStream_t 
     return launch_fwd_bf16<FAM, 4, 1>(a, p, st);
 }
 
+// ---- register-operand forward (fp32 exact) --------------------------------------------------------
+template <int FAM, int NT, int NSH, int ICH>
+int launch_fwd_reg(const LayerArgs& a, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        KV_HIP_CHECK(kv_allow_lds((kan_fwd_reg_kernel<FAM, NT, NSH, ICH>), 160 * 1024));
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
+    hipLaunchKernelGGL((kan_fwd_reg_kernel<FAM, NT, NSH, ICH>), grid, dim3(256), lds, st, a);
+    KV_LAUNCH_CHECK("kan_fwd_reg_kernel");
+    return 0;
+}
+
+template <int FAM, int NT, int NSH>
+int launch_fwd_reg_ich(const LayerArgs& a, int ich, size_t lds, hipStream_t st) {
+    if (ich == 4) return launch_fwd_reg<FAM, NT, NSH, 4>(a, lds, st);
+    if (ich == 2) return launch_fwd_reg<FAM, NT, NSH, 2>(a, lds, st);
+    return launch_fwd_reg<FAM, NT, NSH, 1>(a, lds, st);
+}
+
+// returns 1 when the shape is not covered (caller falls back to the LDS-tile kernel), 0 on success, < 0 on error
+template <int FAM>
+int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
+    if (getenv("KANVIT_NO_REG")) return 1;
+    if (FAM == KV_BSPLINE && !((a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3)) return 1;
+    const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
+    if (a.O % (32 * nt)) return 1;
+    const int nshare = a.groups / a.xmod;
+    const bool share3 = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare == 3 && nt <= 2;
+    const int nsh = share3 ? 3 : 1;
+    if ((a.O & 3) || (a.ldy & 3) || ((uintptr_t)a.y & 15) || ((uintptr_t)a.w & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return 1;
+    const int wrow = 32 * nt * nsh, wrs = 256 / (8 * nt);
+    for (int ich = 4; ich >= 1; ich >>= 1) {
+        const int ic = 2 * ich, kc = ic * a.GP;
+        if (a.I % ic) continue;
+        if (ich == 4 && ((a.ldx & 3) || (a.I & 3) || ((uintptr_t)a.x & 15) ||
+                         (FAM == KV_RBF && a.u && ((a.ldu & 3) || ((uintptr_t)a.u & 15)))))
+            continue;
+        if ((kc + wrs - 1) / wrs > (share3 ? 4 : 8)) continue;                   // W passes held in registers
+        if ((long long)kc * a.O >= (1LL << 30)) continue;
+        size_t lds = sizeof(float) * 2 * (size_t)kc * wrow;
+        if (lds < sizeof(float) * 4 * 32 * 36) lds = sizeof(float) * 4 * 32 * 36;   // epilogue patches alias the W buffers
+        if (lds > 160 * 1024) continue;
+        if (share3) {
+            if constexpr (kv_shared_basis<FAM>()) {
+                if (nt == 1) return launch_fwd_reg_ich<FAM, 1, 3>(a, ich, lds, st);
+                return launch_fwd_reg_ich<FAM, 2, 3>(a, ich, lds, st);
+            }
+        }
+        if (nt == 1) return launch_fwd_reg_ich<FAM, 1, 1>(a, ich, lds, st);
+        if (nt == 2) return launch_fwd_reg_ich<FAM, 2, 1>(a, ich, lds, st);
+        return launch_fwd_reg_ich<FAM, 4, 1>(a, ich, lds, st);
+    }
+    return 1;
+}
+
 template <int FAM>
 int dispatch_fwd(LayerArgs& a, hipStream_t st) {
+    {
+        const int rc = try_fwd_reg<FAM>(a, st);      // register-operand kernel when the shape allows it
+        if (rc <= 0) return rc;
+    }
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     const int nshare = a.groups / a.xmod;
     const bool share3 = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare == 3 && nt <= 2;
