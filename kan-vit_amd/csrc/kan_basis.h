@@ -363,3 +363,71 @@ struct BasisGen {
         }
     }
 };
+
+
+// Derivative generator: next(j) = d phi_j / d(input) for j = 0 .. GP-1 in order (RBF: d/du for j < G, d silu/dx for j = G).
+template <int FAM>
+struct BasisDGen {
+    float x, u, t, sech2, u0, u1, c1, s1, ck, sk, inv_h;
+    float dv[4];
+    int j0, G;
+    bool in;
+    const float* bp;
+
+    __device__ __forceinline__ void init(const BasisArgs& b, float xv, float uv, int feat) {
+        (void)feat;
+        x = xv;
+        u = uv;
+        G = b.G;
+        bp = b.bp;
+        inv_h = b.inv_h;
+        if constexpr (FAM == KV_CHEBY) {
+            t = kv_tanh(xv);
+            sech2 = 1.0f - t * t;
+            u0 = 1.0f;
+            u1 = 2.0f * t;
+        } else if constexpr (FAM == KV_BSPLINE) {
+            float bv[4];
+            in = kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, true);
+        } else if constexpr (FAM == KV_FOURIER) {
+            sincosf(xv, &s1, &c1);
+            ck = c1;
+            sk = s1;
+        }
+    }
+    __device__ __forceinline__ float next(int j) {
+        if constexpr (FAM == KV_LINEAR) {
+            return 1.0f;
+        } else if constexpr (FAM == KV_CHEBY) {     // dT_j/dx = j * U_{j-1}(t) * (1 - t^2)
+            if (j == 0) return 0.0f;
+            if (j == 1) return sech2;
+            const float r = (float)j * u1 * sech2;
+            const float u2 = 2.0f * t * u1 - u0;
+            u0 = u1;
+            u1 = u2;
+            return r;
+        } else if constexpr (FAM == KV_BSPLINE) {
+            if (j >= G) return kv_dsilu(x);
+            const int e = j - (j0 - 3);
+            const float v = e == 0 ? dv[0] : (e == 1 ? dv[1] : (e == 2 ? dv[2] : dv[3]));
+            return (in && e >= 0 && e < 4) ? v : 0.0f;
+        } else if constexpr (FAM == KV_RBF) {
+            if (j >= G) return kv_dsilu(x);
+            const float d = (u - bp[j]) * inv_h;
+            return __expf(-d * d) * (-2.0f * d * inv_h);
+        } else if constexpr (FAM == KV_FOURIER) {   // d cos(kx) = -k sin(kx) for j < G, d sin(kx) = k cos(kx) after
+            if (j == G) {
+                ck = c1;
+                sk = s1;
+            } else if (j != 0) {
+                const float cn = ck * c1 - sk * s1;
+                sk = sk * c1 + ck * s1;
+                ck = cn;
+            }
+            const float kf = (float)((j < G ? j : j - G) + 1);
+            return j < G ? -kf * sk : kf * ck;
+        } else {
+            return 0.0f;                            // SINE is not handled by the register kernels (dfreq reduction)
+        }
+    }
+};
