@@ -965,6 +965,193 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_bf16_kernel(const LayerArgs a) {
 }
 
 // =============================================================================================
+// forward, register-operand form on the bf16 matrix cores (KANVIT_FLAG_BF16_MFMA).  Same idea as kan_fwd_reg_kernel: lane
+// half hf owns ICH whole features per chunk and generates their ICH*GP basis values in order; eight consecutive values are
+// rounded to bf16 and form the A fragment of one v_mfma_f32_32x32x16_bf16.  The weights are repacked once per call
+// (kan_pack_w_fwd_reg_kernel) into the matching image [chunk][k-step][half][n][8 values], so the B fragment is a single
+// ds_read_b128 with lane = column.  GP is a template parameter so the (feature, basis) bookkeeping unrolls statically.
+// =============================================================================================
+// w[groups][K][O] fp32 -> wb[groups][nch][VSTEPS][2][O][8] bf16; value v = 8*ks + e of half h is (j = v / GP, g = v % GP),
+// i.e. natural k = (c*IC + h*ICH + j)*GP + g; v >= ICH*GP pads with zeros.
+__global__ __launch_bounds__(256) void kan_pack_w_fwd_reg_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb,
+                                                                 int K, int O, int GP, int ICH, int vsteps, int nch, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (g, c, ks, h, n) per thread
+    if (e >= total) return;
+    const int n = (int)(e % O);
+    long long r = e / O;
+    const int h = (int)(r & 1);
+    r >>= 1;
+    const int ks = (int)(r % vsteps);
+    r /= vsteps;
+    const int c = (int)(r % nch);
+    const long long g = r / nch;
+    float v[8];
+#pragma unroll
+    for (int j8 = 0; j8 < 8; ++j8) {
+        const int vi = ks * 8 + j8, j = vi / GP, gg = vi - j * GP;
+        const int k = (c * 2 * ICH + h * ICH + j) * GP + gg;
+        v[j8] = (j < ICH && k < K) ? w[(g * K + k) * O + n] : 0.0f;
+    }
+    u32x4 out = {kv_pack_bf16(v[0], v[1]), kv_pack_bf16(v[2], v[3]), kv_pack_bf16(v[4], v[5]), kv_pack_bf16(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(wb + e * 8) = out;
+}
+
+template <int FAM, int GP, int NT, int NSH, int ICH>
+__global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 32 * NT;
+    constexpr int WROW = NSH * BN;
+    constexpr int IC = 2 * ICH;
+    constexpr int VH = ICH * GP;                  // values generated per lane and chunk
+    constexpr int VS = (VH + 7) / 8;              // MFMA k-steps per chunk
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr int TS = 36;
+    constexpr int NV = VS * 2 * BN;               // 16-byte vectors per group and chunk
+    constexpr int WQ = (NV + 255) / 256;
+    constexpr int WSZ = VS * 2 * WROW * 8;        // bf16 elements per W buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int ntn = a.O / BN;
+    const int gs = blockIdx.x / ntn;
+    const int n0 = (blockIdx.x - gs * ntn) * BN;
+    const int nsets = a.groups / NSH;
+    const long long m0 = (long long)blockIdx.y * BM;
+    const int nch = a.I / IC;
+    const int mrem = (m0 + BM <= a.M) ? BM : (int)(a.M - m0);
+    unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [2][VS][2][WROW][8]
+
+    const BasisArgs b = make_basis(a, gs);
+    const int xcol = (NSH == 1 ? gs % a.xmod : gs) * a.I;
+    const int row = wave * 32 + l31;
+    const bool row_ok = row < mrem;
+    const float* xrow = a.x + (m0 + (row_ok ? row : 0)) * a.ldx + xcol + hf * ICH;
+    const float* urow = (RBF && a.u) ? a.u + (m0 + (row_ok ? row : 0)) * a.ldu + (long long)gs * a.I + hf * ICH : xrow;
+
+    u32x4 wreg[NSH][WQ];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int p = 0; p < NSH; ++p) {
+            const int g = (NSH == 1) ? gs : p * nsets + gs;
+            const unsigned short* src = a.wb + (((long long)g * nch + c) * (VS * 2)) * a.O * 8;     // [VS*2][O][8]
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                const int v = tid + q * 256;
+                const int kr = v / BN, n = v & (BN - 1);          // kr = ks*2 + h
+                if (v < NV) wreg[p][q] = *reinterpret_cast<const u32x4*>(src + ((long long)kr * a.O + n0 + n) * 8);
+            }
+        }
+    };
+    auto store_w = [&](int buf) {
+        unsigned short* dst = W_s + (size_t)buf * WSZ;
+#pragma unroll
+        for (int p = 0; p < NSH; ++p)
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                const int v = tid + q * 256;
+                const int kr = v / BN, n = v & (BN - 1);
+                if (v < NV) *reinterpret_cast<u32x4*>(dst + ((size_t)kr * WROW + p * BN + n) * 8) = wreg[p][q];
+            }
+    };
+
+    f32x16 acc[NSH * NT];
+#pragma unroll
+    for (int t = 0; t < NSH * NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    float xv[ICH], uv[ICH];
+    auto load_x = [&](int c) {
+        if constexpr (ICH % 4 == 0) {
+#pragma unroll
+            for (int j4 = 0; j4 < ICH / 4; ++j4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + c * IC + 4 * j4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[4 * j4 + e] = v[e];
+                if (RBF) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(urow + c * IC + 4 * j4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) uv[4 * j4 + e] = w4[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < ICH; ++e) {
+                xv[e] = xrow[c * IC + e];
+                if (RBF) uv[e] = urow[c * IC + e];
+            }
+        }
+    };
+
+    load_w(0);
+    load_x(0);
+    store_w(0);
+    __syncthreads();
+
+    for (int c = 0; c < nch; ++c) {
+        float xc[ICH], uc[ICH];
+#pragma unroll
+        for (int e = 0; e < ICH; ++e) {
+            xc[e] = xv[e];
+            uc[e] = RBF ? uv[e] : 0.0f;
+        }
+        if (c + 1 < nch) {
+            load_w(c + 1);
+            load_x(c + 1);
+        }
+        const unsigned short* wp = W_s + (size_t)(c & 1) * WSZ + ((size_t)hf * WROW + l31) * 8;
+        BasisGen<FAM> gen;
+#pragma unroll
+        for (int ks = 0; ks < VS; ++ks) {
+            float av[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int vi = ks * 8 + e;                        // compile-time after unrolling
+                const int j = vi / GP, g = vi - j * GP;
+                if (vi < VH) {
+                    if (g == 0) gen.init(b, xc[j], uc[j], c * IC + hf * ICH + j);
+                    av[e] = gen.next(g);
+                } else {
+                    av[e] = 0.0f;
+                }
+            }
+            const u32x4 au = {kv_pack_bf16(av[0], av[1]), kv_pack_bf16(av[2], av[3]), kv_pack_bf16(av[4], av[5]),
+                              kv_pack_bf16(av[6], av[7])};
+            const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, au);
+#pragma unroll
+            for (int t = 0; t < NSH * NT; ++t) {
+                const bf16x8_t b8 = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)(2 * ks) * WROW + t * 32) * 8);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nch) store_w((c + 1) & 1);
+        __syncthreads();
+    }
+
+    float* T_w = smem + wave * 32 * TS;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int t = 0; t < NSH * NT; ++t) {
+        const int p = t / NT, nt = t - p * NT;
+        const int g = (NSH == 1) ? gs : p * nsets + gs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T_w[kv_acc_row(r, hf) * TS + l31] = acc[t][r];
+        f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)g * a.O + n0 + nt * 32 + ec);
+        float* yt = a.y + (m0 + wave * 32) * a.ldy + (long long)g * a.O + n0 + nt * 32 + ec;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = er + q * 8;
+            if (wave * 32 + rr < mrem) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(T_w + rr * TS + ec);
+                v += bv;
+                *reinterpret_cast<f32x4*>(yt + (long long)rr * a.ldy) = v;
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // backward w.r.t. the input.  grid (xmod, ceil(M/BM)), 512 threads.
 // Steps t = (feature chunk ci, sharing group p, dY column chunk cn), cn fastest.  Per step the
 // consumers contract dY[:, cn] with W^T into dPhi accumulators; when a contraction ends they park
@@ -1584,6 +1771,87 @@ int launch_fwd_sel(const LayerArgs& a, bool fast, hipStream_t st) {
     return fast ? launch_fwd<FAM, NT, NSH, true>(a, st) : launch_fwd<FAM, NT, NSH, false>(a, st);
 }
 
+// ---- bf16 register-operand forward ------------------------------------------------------------------
+struct FwdRegBf16Plan {
+    bool ok;
+    int gp, nt, nsh, ich, vs, nch;
+    size_t lds, ws_bytes;
+};
+
+FwdRegBf16Plan plan_fwd_reg_bf16(const kanvit_layer_desc* d) {
+    FwdRegBf16Plan p{};
+    if (getenv("KANVIT_NO_REG")) return p;
+    p.gp = gp_of(d);
+    const int fam = d->family;
+    const bool gp_ok = (fam == KANVIT_LINEAR && p.gp == 1) || (fam == KANVIT_CHEBY && p.gp == 5) ||
+                       (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) ||
+                       (fam == KANVIT_RBF && p.gp == 9) || (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 28)) ||
+                       (fam == KANVIT_FOURIER && p.gp == 56);
+    if (!gp_ok) return p;
+    p.nt = d->O <= 32 ? 1 : (d->O <= 64 ? 2 : 4);
+    if (d->O % (32 * p.nt) || (d->O & 3) || (d->ldy & 3)) return p;
+    const int nshare = d->groups / d->x_group_mod;
+    p.nsh = (kv_share_ok(fam, d->flags) && nshare == 3 && p.nt <= 2) ? 3 : 1;
+    p.ich = p.gp >= 28 ? 1 : 8;                   // features per lane half and chunk (instantiated: 8, or 1 for the wide bases)
+    if (d->I % (2 * p.ich)) return p;
+    if (p.ich == 8 && ((d->ldx & 3) || (d->I & 3) || (fam == KANVIT_RBF && (d->ldu & 3)))) return p;
+    p.vs = (p.ich * p.gp + 7) / 8;
+    p.nch = d->I / (2 * p.ich);
+    p.lds = (size_t)2 * p.vs * 2 * 32 * p.nt * p.nsh * 16;
+    if (p.lds < sizeof(float) * 4 * 32 * 36) p.lds = sizeof(float) * 4 * 32 * 36;
+    if (p.lds > 160 * 1024) return p;
+    if ((p.vs * 2 * 32 * p.nt + 255) / 256 > 12) return p;
+    p.ws_bytes = (size_t)d->groups * p.nch * p.vs * 2 * d->O * 16;
+    p.ok = true;
+    return p;
+}
+
+template <int FAM, int GP, int NT, int NSH, int ICH>
+int launch_fwd_reg_bf16(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        KV_HIP_CHECK(kv_allow_lds((kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>), 160 * 1024));
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
+    hipLaunchKernelGGL((kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>), grid, dim3(256), p.lds, st, a);
+    KV_LAUNCH_CHECK("kan_fwd_reg_bf16_kernel");
+    return 0;
+}
+
+template <int FAM, int GP, int ICH>
+int launch_fwd_reg_bf16_shape(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t st) {
+    if (p.nsh == 3) {
+        if constexpr (kv_shared_basis<FAM>()) {
+            if (p.nt == 1) return launch_fwd_reg_bf16<FAM, GP, 1, 3, ICH>(a, p, st);
+            return launch_fwd_reg_bf16<FAM, GP, 2, 3, ICH>(a, p, st);
+        }
+    }
+    if (p.nt == 1) return launch_fwd_reg_bf16<FAM, GP, 1, 1, ICH>(a, p, st);
+    if (p.nt == 2) return launch_fwd_reg_bf16<FAM, GP, 2, 1, ICH>(a, p, st);
+    return launch_fwd_reg_bf16<FAM, GP, 4, 1, ICH>(a, p, st);
+}
+
+template <int FAM>
+int dispatch_fwd_reg_bf16(LayerArgs& a, const FwdRegBf16Plan& p, void* ws, hipStream_t st) {
+    unsigned short* wb = (unsigned short*)ws;
+    const long long total = (long long)a.groups * p.nch * p.vs * 2 * a.O;
+    hipLaunchKernelGGL(kan_pack_w_fwd_reg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w, wb, a.K, a.O, p.gp,
+                       p.ich, p.vs, p.nch, total);
+    KV_LAUNCH_CHECK("kan_pack_w_fwd_reg_kernel");
+    a.wb = wb;
+    if constexpr (FAM == KV_LINEAR) return launch_fwd_reg_bf16_shape<FAM, 1, 8>(a, p, st);
+    if constexpr (FAM == KV_CHEBY) return launch_fwd_reg_bf16_shape<FAM, 5, 8>(a, p, st);
+    if constexpr (FAM == KV_BSPLINE) return launch_fwd_reg_bf16_shape<FAM, 9, 8>(a, p, st);
+    if constexpr (FAM == KV_RBF) return launch_fwd_reg_bf16_shape<FAM, 9, 8>(a, p, st);
+    if constexpr (FAM == KV_SINE) {
+        if (p.gp == 4) return launch_fwd_reg_bf16_shape<FAM, 4, 8>(a, p, st);
+        return launch_fwd_reg_bf16_shape<FAM, 28, 1>(a, p, st);
+    }
+    if constexpr (FAM == KV_FOURIER) return launch_fwd_reg_bf16_shape<FAM, 56, 1>(a, p, st);
+    return kv_fail(KANVIT_EINVAL, "internal: bf16 register forward dispatch");
+}
+
 // ---- bf16 matrix-core forward ----------------------------------------------------------------------
 struct FwdBf16Plan {
     bool ok;
@@ -1969,8 +2237,10 @@ int kanvit_device_count(void) {
 size_t kanvit_layer_fwd_workspace(const kanvit_layer_desc* d) {
     if (!d || !(d->flags & KANVIT_FLAG_BF16_MFMA) || gp_of(d) < 1 || d->groups < 1 || d->x_group_mod < 1 || d->I < 1 || d->O < 1)
         return 0;
-    const FwdBf16Plan p = plan_fwd_bf16(d);
-    return p.ok ? p.ws_bytes : 0;
+    const FwdRegBf16Plan pr = plan_fwd_reg_bf16(d);
+    const FwdBf16Plan p = plan_fwd_bf16(d);          // fallback when the register kernel's alignment checks fail at launch
+    const size_t a1 = pr.ok ? pr.ws_bytes : 0, a2 = p.ok ? p.ws_bytes : 0;
+    return a1 > a2 ? a1 : a2;
 }
 
 int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u, const float* w, const float* bparams,
@@ -1991,6 +2261,15 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
     a.y = y;
     hipStream_t st = (hipStream_t)stream;
     if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !getenv("KANVIT_NO_BF16")) {
+        const FwdRegBf16Plan pr = plan_fwd_reg_bf16(d);
+        if (pr.ok && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)(u ? u : x) | (uintptr_t)(bias ? bias : x)) & 15)) {
+            if (!workspace || workspace_bytes < pr.ws_bytes || ((uintptr_t)workspace & 15))
+                return kv_fail(KANVIT_ENOMEM, "kanvit_layer_fwd: workspace %zu bytes < required %zu (or not 16-byte aligned)",
+                               workspace_bytes, pr.ws_bytes);
+#define KV_CALL(F) dispatch_fwd_reg_bf16<F>(a, pr, workspace, st)
+            KV_FAMILY_SWITCH(d->family, KV_CALL)
+#undef KV_CALL
+        }
         const FwdBf16Plan p = plan_fwd_bf16(d);
         if (p.ok) {
             if (!workspace || workspace_bytes < p.ws_bytes || ((uintptr_t)workspace & 15))
