@@ -1847,6 +1847,172 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_weight_kernel(const LayerArgs a)
     }
 }
 
+// =============================================================================================
+// backward w.r.t. the weights, register form: a barrier-free, LDS-free streaming kernel.
+//   dW[g][i*GP + j][o] = sum_m Phi_j(x[m][i]) * dY[m][g*O + o]
+// The contraction runs over tokens, so the MFMA lane index of the Phi operand is the K row.  K is tiled so that k-tile j of
+// a 32-feature block holds basis function j of 32 DIFFERENT features: lane (l & 31) owns one feature, evaluates its GP
+// basis functions at its token(s) once (BasisGen, a recurrence for Chebyshev) and those GP values ARE its A fragments of
+// the GP k-tiles.  The dY operand is a plain dword load (lane = output column).  Each wave accumulates a
+// [32 features x GP] x [NOT column tiles] block of dW in registers (GP*NOT*16 accumulators) over its slab of tokens;
+// operands are software-prefetched PD blocks ahead (one wave per SIMD: latency is hidden by the prefetch, not occupancy).
+// Work-group = 2 feature blocks x 2 column-tile sets, so x and dY are each fetched by two waves of the same CU.
+// fp32: v_mfma_f32_32x32x2f32, 2 tokens per step (lane half = token parity).  bf16 flag: v_mfma_f32_32x32x16_bf16, 16
+// tokens per step, lane half h owns tokens 8h..8h+7 of the step.  Rows beyond the slab end are clamped for x and zeroed
+// for dY.  Partials go to slab[blockIdx.y][g][k][o]; kan_slab_reduce_kernel sums them in order.
+// grid (basis groups, slabs, ceil(nfb/2)*ceil(nos/2)), 256 threads.
+// =============================================================================================
+template <int FAM, int GP, int NOT, bool BF>
+__global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
+                                                                 int shared) {
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr int TS = BF ? 8 : 1;            // tokens per lane per step
+    constexpr int UB = BF ? 1 : 4;            // steps per prefetch block
+    constexpr int PD = BF ? 3 : 2;            // blocks in flight
+    constexpr int NTOK = TS * UB;             // tokens per lane per block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bg = blockIdx.x;
+    const int fb2 = (nfb + 1) >> 1;
+    const int fb = 2 * ((int)blockIdx.z % fb2) + (wave & 1), os = 2 * ((int)blockIdx.z / fb2) + (wave >> 1);
+    if (fb >= nfb || os >= nos) return;
+    const long long ms = (long long)blockIdx.y * a.rows_per_split;
+    long long me = ms + a.rows_per_split;
+    if (me > a.M) me = a.M;
+    const int len = (int)(me - ms);
+    if (len <= 0) return;
+    const int otpg = a.O / 32;
+    const int f = fb * 32 + l31;
+    const int gx = bg % a.xmod;
+
+    // this wave's column tiles
+    int tg[NOT];          // group of tile i (or -1)
+    long long tcol[NOT];  // column offset of tile i in a dY row
+#pragma unroll
+    for (int i = 0; i < NOT; ++i) {
+        const int tt = os * NOT + i;
+        if (tt < tiles_per_bg) {
+            const int p = tt / otpg;
+            tg[i] = shared ? p * a.xmod + bg : bg;
+            tcol[i] = (long long)tg[i] * a.O + (tt - p * otpg) * 32;
+        } else {
+            tg[i] = -1;
+            tcol[i] = 0;
+        }
+    }
+    const int g0 = shared ? bg : bg;   // basis parameters: identical for every group of a shared launch
+    const BasisArgs b = make_basis(a, g0);
+
+    const float* xcol = a.x + (long long)gx * a.I + f;
+    const float* ucol = RBF ? (a.u ? a.u + (long long)g0 * a.I + f : xcol) : xcol;
+    const long long ldu = RBF ? (a.u ? a.ldu : a.ldx) : a.ldx;
+    const float* dycol = a.dy + l31;
+
+    f32x16 acc[GP][NOT];
+#pragma unroll
+    for (int j = 0; j < GP; ++j)
+#pragma unroll
+        for (int i = 0; i < NOT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+    // token of (block, step u, e): fp32: 2*(blk*UB + u) + hf ; bf16: 16*blk + 8*hf + e
+    float rx[PD][NTOK], ru[RBF ? PD : 1][RBF ? NTOK : 1], rdy[PD][NTOK][NOT];
+    auto tok_of = [&](int blk, int t) -> int { return BF ? (16 * blk + 8 * hf + t) : (2 * (blk * UB + t) + hf); };
+    auto load_block = [&](int q, int blk) {
+#pragma unroll
+        for (int t = 0; t < NTOK; ++t) {
+            int tk = tok_of(blk, t);
+            if (tk > len - 1) tk = len - 1;
+            const long long m = ms + tk;
+            rx[q][t] = xcol[m * a.ldx];
+            if constexpr (RBF) ru[q][t] = ucol[m * ldu];
+#pragma unroll
+            for (int i = 0; i < NOT; ++i) rdy[q][t][i] = dycol[m * a.ldy + tcol[i]];
+        }
+    };
+    const int tok_per_blk = BF ? 16 : 2 * UB;
+    const int nblk = (len + tok_per_blk - 1) / tok_per_blk;
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+        if (q < nblk) load_block(q, q);
+
+    for (int blk0 = 0; blk0 < nblk; blk0 += PD) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            const int blk = blk0 + q;
+            if (blk < nblk) {
+                // take the block out of the ring (this is where the loads are waited for), zero dY of rows past the slab
+                float cx[NTOK], cu[RBF ? NTOK : 1], cdy[NTOK][NOT];
+#pragma unroll
+                for (int t = 0; t < NTOK; ++t) {
+                    const bool ok = tok_of(blk, t) < len;
+                    cx[t] = rx[q][t];
+                    if constexpr (RBF) cu[t] = ru[q][t];
+#pragma unroll
+                    for (int i = 0; i < NOT; ++i) cdy[t][i] = ok ? rdy[q][t][i] : 0.0f;
+                }
+                if (blk + PD < nblk) load_block(q, blk + PD);
+                if constexpr (!BF) {
+#pragma unroll
+                    for (int t = 0; t < NTOK; ++t) {
+                        BasisGen<FAM> gen;
+                        gen.init(b, cx[t], RBF ? cu[t] : 0.0f, f);
+#pragma unroll
+                        for (int j = 0; j < GP; ++j) {
+                            const float av = gen.next(j);
+#pragma unroll
+                            for (int i = 0; i < NOT; ++i)
+                                if (tg[i] >= 0) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    unsigned af[GP][4];
+#pragma unroll
+                    for (int ep = 0; ep < 4; ++ep) {
+                        BasisGen<FAM> g0_, g1_;
+                        g0_.init(b, cx[2 * ep], RBF ? cu[2 * ep] : 0.0f, f);
+                        g1_.init(b, cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f, f);
+#pragma unroll
+                        for (int j = 0; j < GP; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
+                    }
+                    bf16x8_t bfr[NOT];
+#pragma unroll
+                    for (int i = 0; i < NOT; ++i) {
+                        const u32x4 u4 = {kv_pack_bf16(cdy[0][i], cdy[1][i]), kv_pack_bf16(cdy[2][i], cdy[3][i]),
+                                          kv_pack_bf16(cdy[4][i], cdy[5][i]), kv_pack_bf16(cdy[6][i], cdy[7][i])};
+                        bfr[i] = __builtin_bit_cast(bf16x8_t, u4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < GP; ++j) {
+                        const u32x4 a4 = {af[j][0], af[j][1], af[j][2], af[j][3]};
+                        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, a4);
+#pragma unroll
+                        for (int i = 0; i < NOT; ++i)
+                            if (tg[i] >= 0) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[i], acc[j][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // dW partial of this slab: row k = (fb*32 + acc row)*GP + j, 32 contiguous columns per row
+    float* base = a.slab + (long long)blockIdx.y * ((long long)a.groups * a.K * a.O);
+#pragma unroll
+    for (int i = 0; i < NOT; ++i) {
+        if (tg[i] < 0) continue;
+        const int tt = os * NOT + i;
+        const int col0 = (tt % otpg) * 32;
+        float* gb = base + (long long)tg[i] * a.K * a.O + col0 + l31;
+#pragma unroll
+        for (int j = 0; j < GP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int fr = fb * 32 + kv_acc_row(r, hf);
+                gb[((long long)fr * GP + j) * a.O] = acc[j][i][r];
+            }
+    }
+}
+
 // ordered sum of the msplit partial slabs (deterministic; no float atomics)
 __global__ __launch_bounds__(256) void kan_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                               long long total, int msplit) {
@@ -2465,6 +2631,71 @@ int launch_bwd_weight(const LayerArgs& a, const BwPlan& p, bool bf, hipStream_t 
     return bf ? launch_bwd_weight_n<FAM, 1, true>(a, p, st) : launch_bwd_weight_n<FAM, 1, false>(a, p, st);
 }
 
+// ---- register-form (streaming) weight gradient -----------------------------------------------------
+struct BwRegPlan {
+    bool ok;
+    int gp, nt, nfb, nos, tiles_per_bg, nbg, shared, slabs;
+    long long rows_per_slab;
+    size_t ws_bytes;
+};
+
+BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
+    BwRegPlan p{};
+    if (getenv("KANVIT_NO_REG") || getenv("KANVIT_NO_REG_BW")) return p;
+    p.gp = gp_of(d);
+    const int fam = d->family;
+    if (fam == KANVIT_LINEAR && p.gp == 1) p.nt = 6;
+    else if (fam == KANVIT_CHEBY && p.gp == 5) p.nt = 3;
+    else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) p.nt = 1;
+    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 1;
+    else return p;
+    if (d->I % 32 || d->O % 32 || d->M < 256) return p;
+    const int nshare = d->groups / d->x_group_mod;
+    p.shared = (kv_share_ok(fam, d->flags) && nshare > 1) ? 1 : 0;
+    p.nbg = p.shared ? d->x_group_mod : d->groups;
+    p.tiles_per_bg = (p.shared ? nshare : 1) * (d->O / 32);
+    p.nfb = d->I / 32;
+    p.nos = (p.tiles_per_bg + p.nt - 1) / p.nt;
+    const long long per = (long long)p.nbg * ((p.nfb + 1) / 2) * ((p.nos + 1) / 2);
+    long long r = 1;
+    while ((long long)N_CU * r < per) ++r;
+    long long S = (long long)N_CU * r / per;
+    const long long smax = d->M / 256;
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    if (S > 65535) S = 65535;
+    long long rps = (d->M + S - 1) / S;
+    rps = (rps + 15) / 16 * 16;
+    p.rows_per_slab = rps;
+    p.slabs = (int)((d->M + rps - 1) / rps);
+    if ((long long)d->ldy * 1 >= (1LL << 40) || per * 1 > 65535LL * 65535LL) return p;
+    if (((p.nfb + 1) / 2) * ((p.nos + 1) / 2) > 65535) return p;
+    p.ws_bytes = p.slabs > 1 ? sizeof(float) * (size_t)p.slabs * d->groups * ((size_t)d->I * p.gp) * d->O : 0;
+    p.ok = true;
+    return p;
+}
+
+template <int FAM, int GP, int NOT>
+int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+    dim3 grid((unsigned)p.nbg, (unsigned)p.slabs, (unsigned)(((p.nfb + 1) / 2) * ((p.nos + 1) / 2)));
+    if (bf)
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared);
+    else
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared);
+    KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
+    return 0;
+}
+
+int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+    switch (family) {
+        case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
+        case KANVIT_CHEBY: return launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
+        case KANVIT_BSPLINE: return launch_bwd_weight_reg<KV_BSPLINE, 9, 1>(a, p, bf, st);
+        case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 1>(a, p, bf, st);
+        default: return kv_fail(KANVIT_EINVAL, "internal: register weight-gradient dispatch");
+    }
+}
+
 #define KV_FAMILY_SWITCH(fam, CALL)                                   \
     switch (fam) {                                                    \
         case KANVIT_LINEAR: return CALL(KV_LINEAR);                   \
@@ -2615,6 +2846,8 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
 
 size_t kanvit_layer_bwd_weight_workspace(const kanvit_layer_desc* d) {
     if (!d || gp_of(d) < 1 || d->groups < 1 || d->I < 1 || d->O < 1) return 0;
+    const BwRegPlan pr = plan_bwd_weight_reg(d);
+    if (pr.ok) return pr.ws_bytes;
     const BwPlan p = plan_bwd_weight(d);
     if (p.msplit <= 1) return 0;
     return sizeof(float) * (size_t)p.msplit * d->groups * ((size_t)d->I * gp_of(d)) * d->O;
@@ -2641,6 +2874,26 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
     a.u = u;
     a.bp = bparams;
     a.dy = dy;
+    {
+        const BwRegPlan pr = plan_bwd_weight_reg(d);
+        if (pr.ok) {
+            hipStream_t st = (hipStream_t)stream;
+            const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !getenv("KANVIT_NO_BF16");
+            a.rows_per_split = pr.rows_per_slab;
+            a.msplit = pr.slabs;
+            a.slab = (pr.slabs > 1) ? (float*)workspace : dw;
+            if (int rc = dispatch_bwd_weight_reg(d->family, a, pr, bf, st)) return rc;
+            if (pr.slabs > 1) {
+                const long long total = (long long)d->groups * a.K * d->O;
+                long long nb = (total + 255) / 256;
+                if (nb > 8 * N_CU) nb = 8 * N_CU;
+                hipLaunchKernelGGL(kan_slab_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)workspace, dw, total,
+                                   pr.slabs);
+                KV_LAUNCH_CHECK("kan_slab_reduce_kernel");
+            }
+            return 0;
+        }
+    }
     a.IC = p.ic;
     a.msplit = p.msplit;
     a.nchunks_n = p.nchunks_n;
