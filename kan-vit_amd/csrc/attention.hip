@@ -293,6 +293,228 @@ __global__ __launch_bounds__(ATHR) void attn_fwd_kernel(const AttnArgs a) {
 }
 
 // =============================================================================================
+// forward, second form (D == 32*DT, 16-byte aligned operands).  Same mathematics and tile orientation as attn_fwd_kernel;
+// what changes is where the operands live:
+//   * Q never touches the LDS: the B operand of S^T = K.Q^T is (d, query = lane), i.e. a piece of the lane's OWN query
+//     row, loaded as float4 from global.  The contraction order over d is free, so in fp32 lane half h takes
+//     d = 16*DT*h + s at k-step s (one contiguous half row) instead of d = 2s + h.
+//   * O is stored straight from the accumulators: registers 4q..4q+3 of O^T are 4 consecutive d of the lane's query row
+//     (one float4 per (dt, q)); no staging tile, so the only barrier of the kernel is the one after the K/V fill.
+//   * 1/sum is applied to the 32*DT output values, not to the 16*nkt probabilities.
+//   * bf16 mode keeps K and V in the LDS AS bf16, in the order the matrix core wants them: K rows [key][D + 8] (the
+//     A fragment of S^T is one ds_read_b128), V transposed [d][NP + 8] with the 32 keys of a tile stored in accumulator
+//     order (slot 16*s2 + 8*h + e <-> key 16*s2 + 8*(e>>2) + 4*h + (e&3)), so the A fragment of O^T = V^T.P is one
+//     ds_read_b128 too.  62 KiB for N = 197: two work-groups per CU, one loading while the other computes.
+// fp32: 8 waves, one query tile each (2 waves per SIMD hide each other's LDS latency); bf16: 4 waves, 2 trips.
+// =============================================================================================
+__device__ __forceinline__ int kv_key_slot(int ko) {      // position of key offset ko (0..31) inside its tile, bf16 V^T image
+    const int w = ko & 15;
+    return (ko & 16) + 8 * ((w >> 2) & 1) + 4 * (w >> 3) + (w & 3);
+}
+
+template <int DT, int NKT, bool BF>
+__global__ __launch_bounds__(BF ? 256 : 512, 2) void attn_fwd2_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT;
+    constexpr int NW = BF ? 4 : 8;
+    constexpr int NTHR = NW * 64;
+    constexpr int KS = D + 1;          // fp32 row stride (floats)
+    constexpr int KB = D + 8;          // bf16 K row stride (elements)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32;
+    const int VB = NP + 8;             // bf16 V^T row stride (elements)
+    float* K_s = smem;                 // fp32: [NP][KS]
+    float* V_s = K_s + NP * KS;        // fp32: [NP][KS]
+    unsigned short* Kb = reinterpret_cast<unsigned short*>(smem);   // bf16: [NP][KB]
+    unsigned short* Vt = Kb + NP * KB;                              // bf16: [D][VB]
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    float* ob = a.out + bi * a.osb + hi * a.osh;
+
+    if constexpr (!BF) {
+        load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, NTHR, true);
+        load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, NTHR, true);
+    } else {
+        constexpr int C4 = D / 4;                       // float4 per row
+        const int c4 = (tid % C4) * 4, r0 = tid / C4;
+        constexpr int RP = NTHR / C4;                   // rows per pass
+        // K: [key][d] rows, 4 floats -> 4 bf16 (8 bytes)
+        for (int rb = 0; rb < NP; rb += 4 * RP) {
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int key = rb + q * RP + r0;
+                f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (key < N) t = *reinterpret_cast<const f32x4*>(kb + (long long)key * a.ksn + c4);
+                v[q] = t;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int key = rb + q * RP + r0;
+                if (key < NP) {
+                    unsigned* dst = reinterpret_cast<unsigned*>(Kb + key * KB + c4);
+                    dst[0] = kv_pk(v[q][0], v[q][1]);
+                    dst[1] = kv_pk(v[q][2], v[q][3]);
+                }
+            }
+        }
+        // V: key pairs (2m, 2m+1) are adjacent slots of the transposed image
+        const int NPAIR = NP / 2;
+        for (int pb = 0; pb < NPAIR; pb += 2 * RP) {
+            f32x4 v0[2], v1[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int key = 2 * (pb + q * RP + r0);
+                f32x4 t0 = {0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;
+                if (key < N) t0 = *reinterpret_cast<const f32x4*>(vb + (long long)key * a.vsn + c4);
+                if (key + 1 < N) t1 = *reinterpret_cast<const f32x4*>(vb + (long long)(key + 1) * a.vsn + c4);
+                v0[q] = t0;
+                v1[q] = t1;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int key = 2 * (pb + q * RP + r0);
+                if (key < NP) {
+                    const int pos = (key & ~31) + kv_key_slot(key & 31);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *reinterpret_cast<unsigned*>(Vt + (c4 + e) * VB + pos) = kv_pk(v0[q][e], v1[q][e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const float sc2 = a.scale * LOG2E;
+    const int niter = (nkt + NW - 1) / NW;
+    for (int it = 0; it < niter; ++it) {
+        const int qt = it * NW + wave;
+        if (qt >= nkt) break;                  // no barriers below: a wave without a tile is done
+        const int qrow = qt * 32 + l31;
+        const bool qok = qrow < N;
+        const float* qp = qb + (long long)(qok ? qrow : 0) * a.qsn;
+
+        float qf[BF ? 1 : 16 * DT];
+        bf16x8_t qfb[BF ? 2 * DT : 1];
+        if constexpr (BF) {
+#pragma unroll
+            for (int ks = 0; ks < 2 * DT; ++ks) {
+                f32x4 u0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 8 * hf);
+                f32x4 u1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 8 * hf + 4);
+                if (!qok) { u0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; u1 = u0; }
+                const u32x4 u = {kv_pk(u0[0], u0[1]), kv_pk(u0[2], u0[3]), kv_pk(u1[0], u1[1]), kv_pk(u1[2], u1[3])};
+                qfb[ks] = __builtin_bit_cast(bf16x8_t, u);
+            }
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < 4 * DT; ++s4) {
+                f32x4 u0 = *reinterpret_cast<const f32x4*>(qp + 16 * DT * hf + 4 * s4);
+                if (!qok) u0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[4 * s4 + e] = u0[e];
+            }
+        }
+
+        f32x16 sacc[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
+            if (j < nkt) {
+                if constexpr (BF) {
+                    const unsigned short* kp = Kb + (j * 32 + l31) * KB + 8 * hf;
+#pragma unroll
+                    for (int ks = 0; ks < 2 * DT; ++ks)
+                        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(kp + 16 * ks), qfb[ks],
+                                                                          sacc[j], 0, 0, 0);
+                } else {
+                    const float* kp = K_s + (j * 32 + l31) * KS + 16 * DT * hf;
+#pragma unroll
+                    for (int s = 0; s < 16 * DT; ++s)
+                        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[s], qf[s], sacc[j], 0, 0, 0);
+                }
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+                if (j == nkt - 1 || a.causal) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = j * 32 + kv_acc_row(r, hf);
+                        const bool dead = (key >= N) || (a.causal && key > qrow);
+                        sacc[j][r] = dead ? -INFINITY : sacc[j][r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mxs = (mx == -INFINITY) ? 0.0f : mx * sc2;
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(sacc[j][r] * sc2 - mxs);
+                    sacc[j][r] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+                if constexpr (BF) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8_t pb = kv_acc8(sacc[j], s2);
+                        const unsigned short* vp = Vt + l31 * VB + j * 32 + 16 * s2 + 8 * hf;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+                            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(vp + dt * 32 * VB), pb,
+                                                                               oacc[dt], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float* vp = V_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+                            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], sacc[j][r], oacc[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (qok) {
+            float* op = ob + (long long)qrow * a.osn + 4 * hf;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
+                    *reinterpret_cast<f32x4*>(op + dt * 32 + 8 * q) = v;
+                }
+            if (hf == 0 && a.lse) a.lse[(long long)bh * N + qrow] = mx * a.scale + logf(sum);
+        }
+    }
+}
+
+// =============================================================================================
 // backward helper: delta[b,h,n] = sum_d dO * O   (utils.py:286, "D")
 // =============================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
@@ -625,8 +847,30 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
     return 0;
 }
 
+template <int DT, int NKT, bool BF>
+int launch_fwd2(const AttnArgs& a, hipStream_t st) {
+    constexpr int D = 32 * DT;
+    const int NP = a.nkt * 32;
+    const size_t lds = BF ? sizeof(unsigned short) * ((size_t)NP * (D + 8) + (size_t)D * (NP + 8))
+                          : sizeof(float) * (size_t)2 * NP * (D + 1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        KV_HIP_CHECK(kv_allow_lds(attn_fwd2_kernel<DT, NKT, BF>, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_fwd2_kernel<DT, NKT, BF>), dim3((unsigned)(a.B * a.H)), dim3(BF ? 256 : 512), lds, st, a);
+    KV_LAUNCH_CHECK("attn_fwd2_kernel");
+    return 0;
+}
+
 template <int DT, bool BF>
 int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
+    if (a.vec && a.D == 32 * DT && ((uintptr_t)a.out % 16 == 0) && !getenv("KANVIT_ATTN_V1")) {
+        if (a.nkt <= 1) return launch_fwd2<DT, 1, BF>(a, st);
+        if (a.nkt <= 2) return launch_fwd2<DT, 2, BF>(a, st);
+        if (a.nkt <= 4) return launch_fwd2<DT, 4, BF>(a, st);
+        if (a.nkt <= 7) return launch_fwd2<DT, 7, BF>(a, st);
+    }
     if (a.nkt <= 1) return launch_fwd<DT, 1, BF>(a, st);
     if (a.nkt <= 2) return launch_fwd<DT, 2, BF>(a, st);
     if (a.nkt <= 4) return launch_fwd<DT, 4, BF>(a, st);
