@@ -805,6 +805,321 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
     }
 }
 
+// =============================================================================================
+// backward, second form (D == 32*DT, aligned operands): the same two kernels with the operand placement of attn_fwd2_kernel.
+//   * the stationary tile's fragments (K, V rows of the wave's keys; Q, dO rows of the wave's queries) are B operands
+//     indexed (d, lane) -> loaded from the lane's own global row, no staging, no barriers;
+//   * dK^T / dV^T / dQ^T accumulators hold 4 consecutive d of the lane's own row per register quad -> float4 stores;
+//   * bf16 mode keeps bf16 images of the swept operand in the LDS: a row image [n][D + 8] for the first products and a
+//     transposed image [d][NP + 8] (tile rows in accumulator order, kv_key_slot) for the second products, so every A
+//     fragment is one ds_read_b128;
+//   * 8 waves, one tile each: one barrier per kernel (after the LDS fill).
+// =============================================================================================
+// Fill bf16 images of src[n][D] (fp32, row stride `stride`): rowimg[n][D + 8] and/or timg[d][NP + 8]; rows >= N are zero.
+template <int DT, int NTHR>
+__device__ __forceinline__ void fill_bf16_images(unsigned short* __restrict__ rowimg, unsigned short* __restrict__ timg,
+                                                 const float* __restrict__ src, long long stride, int NP, int N, int tid) {
+    constexpr int D = 32 * DT, C4 = D / 4, RP = NTHR / C4, KB = D + 8;
+    const int VB = NP + 8;
+    const int c4 = (tid % C4) * 4, r0 = tid / C4;
+    const int NPAIR = NP / 2;
+    for (int pb = 0; pb < NPAIR; pb += 4 * RP) {
+        f32x4 v0[4], v1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = 2 * (pb + q * RP + r0);
+            f32x4 t0 = {0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;
+            if (n < N) t0 = *reinterpret_cast<const f32x4*>(src + (long long)n * stride + c4);
+            if (n + 1 < N) t1 = *reinterpret_cast<const f32x4*>(src + (long long)(n + 1) * stride + c4);
+            v0[q] = t0;
+            v1[q] = t1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = 2 * (pb + q * RP + r0);
+            if (n < NP) {
+                if (rowimg) {
+                    unsigned* d0 = reinterpret_cast<unsigned*>(rowimg + n * KB + c4);
+                    d0[0] = kv_pk(v0[q][0], v0[q][1]);
+                    d0[1] = kv_pk(v0[q][2], v0[q][3]);
+                    unsigned* d1 = reinterpret_cast<unsigned*>(rowimg + (n + 1) * KB + c4);
+                    d1[0] = kv_pk(v1[q][0], v1[q][1]);
+                    d1[1] = kv_pk(v1[q][2], v1[q][3]);
+                }
+                if (timg) {
+                    const int pos = (n & ~31) + kv_key_slot(n & 31);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(timg + (c4 + e) * VB + pos) = kv_pk(v0[q][e], v1[q][e]);
+                }
+            }
+        }
+    }
+}
+
+// B-operand fragments of one global row: bf16: 2*DT fragments of 8 consecutive d (16*ks + 8*hf ..); fp32: the half row
+// d = 16*DT*hf + s.  ok == false gives zeros.
+template <int DT, bool BF>
+__device__ __forceinline__ void row_frags(const float* __restrict__ rowp, bool ok, int hf, float (&f)[BF ? 1 : 16 * DT],
+                                          bf16x8_t (&fb)[BF ? 2 * DT : 1]) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int ks = 0; ks < 2 * DT; ++ks) {
+            f32x4 u0 = {0.0f, 0.0f, 0.0f, 0.0f}, u1 = u0;
+            if (ok) {
+                u0 = *reinterpret_cast<const f32x4*>(rowp + 16 * ks + 8 * hf);
+                u1 = *reinterpret_cast<const f32x4*>(rowp + 16 * ks + 8 * hf + 4);
+            }
+            const u32x4 u = {kv_pk(u0[0], u0[1]), kv_pk(u0[2], u0[3]), kv_pk(u1[0], u1[1]), kv_pk(u1[2], u1[3])};
+            fb[ks] = __builtin_bit_cast(bf16x8_t, u);
+        }
+    } else {
+#pragma unroll
+        for (int s4 = 0; s4 < 4 * DT; ++s4) {
+            f32x4 u0 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (ok) u0 = *reinterpret_cast<const f32x4*>(rowp + 16 * DT * hf + 4 * s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * s4 + e] = u0[e];
+        }
+    }
+}
+
+// accumulator [d][row = lane] -> the lane's global row (registers 4q..4q+3 = d = 32*dt + 8q + 4hf + 0..3)
+template <int DT>
+__device__ __forceinline__ void store_acc_rows(float* __restrict__ rowp, const f32x16 (&acc)[DT], int hf, float mul) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[dt][4 * q] * mul, acc[dt][4 * q + 1] * mul, acc[dt][4 * q + 2] * mul, acc[dt][4 * q + 3] * mul};
+            *reinterpret_cast<f32x4*>(rowp + dt * 32 + 8 * q + 4 * hf) = v;
+        }
+}
+
+template <int DT, bool BF>
+__global__ __launch_bounds__(512) void attn_bwd_kv2_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, KS = D + 1, KB = D + 8, NTHR = 512, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32, VB = NP + 8;
+    // fp32: Q_s[NP][KS] dO_s[NP][KS] | bf16: Qr[NP][KB] dOr[NP][KB] Qt[D][VB] dOt[D][VB]; then lse_s[NP] dl_s[NP]
+    float* Q_s = smem;
+    float* dO_s = Q_s + NP * KS;
+    unsigned short* Qr = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* dOr = Qr + NP * KB;
+    unsigned short* Qt = dOr + NP * KB;
+    unsigned short* dOt = Qt + D * VB;
+    float* lse_s = BF ? reinterpret_cast<float*>(dOt + D * VB) : dO_s + NP * KS;
+    float* dl_s = lse_s + NP;
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    float* dkb = a.dk + bi * a.ksb + hi * a.ksh;
+    float* dvb = a.dv + bi * a.vsb + hi * a.vsh;
+
+    if constexpr (BF) {
+        fill_bf16_images<DT, NTHR>(Qr, Qt, qb, a.qsn, NP, N, tid);
+        fill_bf16_images<DT, NTHR>(dOr, dOt, dob, a.osn, NP, N, tid);
+    } else {
+        load_tile<DT>(Q_s, qb, a.qsn, 0, NP, N, D, tid, NTHR, true);
+        load_tile<DT>(dO_s, dob, a.osn, 0, NP, N, D, tid, NTHR, true);
+    }
+    for (int n = tid; n < NP; n += NTHR) {
+        lse_s[n] = (n < N) ? a.lse_in[(long long)bh * N + n] * LOG2E : INFINITY;   // exp2(-inf) = 0 on pad rows
+        dl_s[n] = (n < N) ? a.delta_in[(long long)bh * N + n] : 0.0f;
+    }
+    __syncthreads();
+    const float sc2 = a.scale * LOG2E;
+
+    for (int jt = wave; jt < nkt; jt += NW) {
+        const int key = jt * 32 + l31;
+        const bool key_ok = key < N;
+        float kf[BF ? 1 : 16 * DT], vf[BF ? 1 : 16 * DT];
+        bf16x8_t kbf[BF ? 2 * DT : 1], vbf[BF ? 2 * DT : 1];
+        row_frags<DT, BF>(kb + (long long)(key_ok ? key : 0) * a.ksn, key_ok, hf, kf, kbf);
+        row_frags<DT, BF>(vb + (long long)(key_ok ? key : 0) * a.vsn, key_ok, hf, vf, vbf);
+
+        f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[dt][r] = 0.0f;
+                dvacc[dt][r] = 0.0f;
+            }
+
+        for (int qt = 0; qt < nkt; ++qt) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            if constexpr (BF) {
+                const unsigned short* qp = Qr + (qt * 32 + l31) * KB + 8 * hf;
+                const unsigned short* dp = dOr + (qt * 32 + l31) * KB + 8 * hf;
+#pragma unroll
+                for (int ks = 0; ks < 2 * DT; ++ks) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(qp + 16 * ks), kbf[ks], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(dp + 16 * ks), vbf[ks], pacc, 0, 0, 0);
+                }
+            } else {
+                const float* qp = Q_s + (qt * 32 + l31) * KS + 16 * DT * hf;
+                const float* dp = dO_s + (qt * 32 + l31) * KS + 16 * DT * hf;
+#pragma unroll
+                for (int s = 0; s < 16 * DT; ++s) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[s], kf[s], sacc, 0, 0, 0);    // S[q][key]
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[s], vf[s], pacc, 0, 0, 0);    // dP[q][key]
+                }
+            }
+            // p = exp(s*scale - lse), ds = p * scale * (dp - delta)        (utils.py:278-287)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = qt * 32 + kv_acc_row(r, hf);
+                float p = exp2f(sacc[r] * sc2 - lse_s[qrow]);
+                if (!key_ok || (a.causal && key > qrow)) p = 0.0f;
+                sacc[r] = p;
+                pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+            if constexpr (BF) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t pb = kv_acc8(sacc, s2), db = kv_acc8(pacc, s2);
+                    const int off = l31 * VB + qt * 32 + 16 * s2 + 8 * hf;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(dOt + off + dt * 32 * VB), pb,
+                                                                            dvacc[dt], 0, 0, 0);
+                        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Qt + off + dt * 32 * VB), db,
+                                                                            dkacc[dt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (qt * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dO_s[row + dt * 32], sacc[r], dvacc[dt], 0, 0, 0);
+                        dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Q_s[row + dt * 32], pacc[r], dkacc[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (key_ok) {
+            store_acc_rows<DT>(dkb + (long long)key * a.ksn, dkacc, hf, 1.0f);
+            store_acc_rows<DT>(dvb + (long long)key * a.vsn, dvacc, hf, 1.0f);
+        }
+    }
+}
+
+template <int DT, bool BF>
+__global__ __launch_bounds__(512) void attn_bwd_q2_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, KS = D + 1, KB = D + 8, NTHR = 512, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32, VB = NP + 8;
+    float* K_s = smem;                    // fp32: K_s[NP][KS] V_s[NP][KS]
+    float* V_s = K_s + NP * KS;
+    unsigned short* Kr = reinterpret_cast<unsigned short*>(smem);   // bf16: Kr[NP][KB] Vr[NP][KB] Kt[D][VB]
+    unsigned short* Vr = Kr + NP * KB;
+    unsigned short* Kt = Vr + NP * KB;
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
+
+    if constexpr (BF) {
+        fill_bf16_images<DT, NTHR>(Kr, Kt, kb, a.ksn, NP, N, tid);
+        fill_bf16_images<DT, NTHR>(Vr, nullptr, vb, a.vsn, NP, N, tid);
+    } else {
+        load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, NTHR, true);
+        load_tile<DT>(V_s, vb, a.vsn, 0, NP, N, D, tid, NTHR, true);
+    }
+    __syncthreads();
+    const float sc2 = a.scale * LOG2E;
+
+    for (int qt = wave; qt < nkt; qt += NW) {
+        const int qrow = qt * 32 + l31;
+        const bool q_ok = qrow < N;
+        float qf[BF ? 1 : 16 * DT], dof[BF ? 1 : 16 * DT];
+        bf16x8_t qbf[BF ? 2 * DT : 1], dobf[BF ? 2 * DT : 1];
+        row_frags<DT, BF>(qb + (long long)(q_ok ? qrow : 0) * a.qsn, q_ok, hf, qf, qbf);
+        row_frags<DT, BF>(dob + (long long)(q_ok ? qrow : 0) * a.osn, q_ok, hf, dof, dobf);
+        const float lse2 = q_ok ? a.lse_in[(long long)bh * N + qrow] * LOG2E : INFINITY;
+        const float dl = q_ok ? a.delta_in[(long long)bh * N + qrow] : 0.0f;
+
+        f32x16 dqacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+
+        for (int j = 0; j < nkt; ++j) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            if constexpr (BF) {
+                const unsigned short* kp = Kr + (j * 32 + l31) * KB + 8 * hf;
+                const unsigned short* vp = Vr + (j * 32 + l31) * KB + 8 * hf;
+#pragma unroll
+                for (int ks = 0; ks < 2 * DT; ++ks) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(kp + 16 * ks), qbf[ks], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(vp + 16 * ks), dobf[ks], pacc, 0, 0, 0);
+                }
+            } else {
+                const float* kp = K_s + (j * 32 + l31) * KS + 16 * DT * hf;
+                const float* vp = V_s + (j * 32 + l31) * KS + 16 * DT * hf;
+#pragma unroll
+                for (int s = 0; s < 16 * DT; ++s) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[s], qf[s], sacc, 0, 0, 0);    // S^T[key][q]
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[s], dof[s], pacc, 0, 0, 0);   // dP^T[key][q]
+                }
+            }
+            const bool edge = (j == nkt - 1) || a.causal;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = exp2f(sacc[r] * sc2 - lse2);
+                if (edge) {
+                    const int key = j * 32 + kv_acc_row(r, hf);
+                    if (key >= N || (a.causal && key > qrow)) p = 0.0f;
+                }
+                pacc[r] = p * a.scale * (pacc[r] - dl);                                          // dS^T
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            if constexpr (BF) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t db = kv_acc8(pacc, s2);
+                    const unsigned short* kr = Kt + l31 * VB + j * 32 + 16 * s2 + 8 * hf;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(kr + dt * 32 * VB), db, dqacc[dt],
+                                                                            0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* kr = K_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[dt * 32], pacc[r], dqacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (q_ok) store_acc_rows<DT>(dqb + (long long)qrow * a.qsn, dqacc, hf, 1.0f);
+    }
+}
+
 int check_desc(const kanvit_attn_desc* d, const char* who) {
     if (!d) return kv_fail(KANVIT_EINVAL, "%s: null descriptor", who);
     if (d->B < 0 || d->H < 1 || d->N < 1 || d->D < 1) return kv_fail(KANVIT_EINVAL, "%s: bad sizes", who);
@@ -879,7 +1194,35 @@ int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
 }
 
 template <int DT, bool BF>
+int launch_bwd2(const AttnArgs& a, hipStream_t st) {
+    constexpr int D = 32 * DT;
+    const int NP = a.nkt * 32;
+    const size_t row = sizeof(unsigned short) * (size_t)NP * (D + 8), tr = sizeof(unsigned short) * (size_t)D * (NP + 8);
+    const size_t f32img = sizeof(float) * (size_t)NP * (D + 1);
+    const size_t lds_kv = (BF ? 2 * row + 2 * tr : 2 * f32img) + sizeof(float) * 2 * (size_t)NP;
+    const size_t lds_q = BF ? 2 * row + tr : 2 * f32img;
+    static bool attr_done = false;
+    if (!attr_done) {
+        KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv2_kernel<DT, BF>), 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds((attn_bwd_q2_kernel<DT, BF>), 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_kv2_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_kv, st, a);
+    KV_LAUNCH_CHECK("attn_bwd_kv2_kernel");
+    hipLaunchKernelGGL((attn_bwd_q2_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_q, st, a);
+    KV_LAUNCH_CHECK("attn_bwd_q2_kernel");
+    return 0;
+}
+
+template <int DT, bool BF>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
+    if (a.vec && a.D == 32 * DT && !getenv("KANVIT_ATTN_V1") &&
+        (((uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) % 16 == 0)) {
+        const int NPc = a.nkt * 32;
+        const size_t need = BF ? sizeof(unsigned short) * ((size_t)2 * NPc * (32 * DT + 8) + (size_t)2 * 32 * DT * (NPc + 8)) + 8 * (size_t)NPc
+                               : sizeof(float) * ((size_t)2 * NPc * (32 * DT + 1) + 2 * (size_t)NPc);
+        if (need <= 160 * 1024) return launch_bwd2<DT, BF>(a, st);
+    }
     constexpr int KS = 32 * DT + 1;
     const int NP = a.nkt * 32;
     const size_t lds_kv = sizeof(float) * ((size_t)2 * NP * KS + 2 * (size_t)NP + (size_t)4 * 32 * KS);
