@@ -20,6 +20,29 @@ import torch.nn.functional as F
 from . import ops
 
 
+class _StackParams(torch.autograd.Function):
+    """torch.stack over per-head parameters whose backward costs ONE kernel.
+
+    Stock stack hands autograd 3*H strided slices of the packed-weight gradient; AccumulateGrad then clones each one
+    (432 five-microsecond copies per ViT-B step).  Here the incoming gradient is made contiguous once and the per-parameter
+    gradients are its unbound slices: contiguous, uniquely referenced, so AccumulateGrad adopts them without a copy."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        return torch.stack(tensors)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad.contiguous().unbind(0)
+
+
+def stack_params(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    tensors = list(tensors)
+    if any(t.requires_grad for t in tensors) and torch.is_grad_enabled():
+        return _StackParams.apply(*tensors)
+    return torch.stack(tensors)
+
+
 def linear_cfg(lin: torch.nn.Linear) -> ops.LayerCfg:
     return ops.LayerCfg(family=ops.LINEAR, I=lin.in_features, O=lin.out_features, G=1)
 
@@ -60,9 +83,9 @@ def run_qkv(q_layers: Sequence, k_layers: Sequence, v_layers: Sequence, x2d: tor
     # Pack ALL 3*H layers with one stack + one layout transform (a handful of launches) instead of a
     # permute-copy per head (3*H launches forward and again backward: 880 tiny kernels per ViT-B step).
     if isinstance(layers[0], torch.nn.Linear):
-        w = torch.stack([m.weight for m in layers]).permute(0, 2, 1)
+        w = stack_params([m.weight for m in layers]).permute(0, 2, 1)
         bp = None
-        bias = None if layers[0].bias is None else torch.stack([m.bias for m in layers])
+        bias = None if layers[0].bias is None else stack_params([m.bias for m in layers])
     else:
         w, bp, bias = type(layers[0]).kan_pack_grouped(layers)
     u = None

@@ -35,7 +35,7 @@ class ChebyKANLayer(nn.Module):
 
     @staticmethod
     def kan_pack_grouped(layers):
-        c = torch.stack([m.cheby_coeffs for m in layers])                    # [g, I, O, D+1]
+        c = grouped.stack_params([m.cheby_coeffs for m in layers])                    # [g, I, O, D+1]
         g, i, o, d1 = c.shape
         return c.permute(0, 1, 3, 2).reshape(g, i * d1, o), None, None
 

@@ -126,10 +126,10 @@ class KANLinear(torch.nn.Module):
     @staticmethod
     def kan_pack_grouped(layers):
         l0 = layers[0]
-        sw = torch.stack([m.spline_weight for m in layers])                  # [g, O, I, nb]
+        sw = grouped.stack_params([m.spline_weight for m in layers])                  # [g, O, I, nb]
         if l0.enable_standalone_scale_spline:
-            sw = sw * torch.stack([m.spline_scaler for m in layers]).unsqueeze(-1)
-        bw = torch.stack([m.base_weight for m in layers])                    # [g, O, I]
+            sw = sw * grouped.stack_params([m.spline_scaler for m in layers]).unsqueeze(-1)
+        bw = grouped.stack_params([m.base_weight for m in layers])                    # [g, O, I]
         w = torch.cat([sw.permute(0, 2, 3, 1), bw.permute(0, 2, 1).unsqueeze(2)], dim=2)   # [g, I, nb+1, O]
         g, i, nb1, o = w.shape
         return w.reshape(g, i * nb1, o), torch.stack([m.grid.reshape(-1) for m in layers]), None

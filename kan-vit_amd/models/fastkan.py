@@ -76,12 +76,12 @@ class FastKANLayer(nn.Module):
         l0 = layers[0]
         i, gr, o = l0.input_dim, l0.num_grids, l0.output_dim
         g = len(layers)
-        w = torch.stack([m.spline_linear.weight for m in layers]).view(g, o, i, gr).permute(0, 2, 3, 1)   # [g, I, G, O]
+        w = grouped.stack_params([m.spline_linear.weight for m in layers]).view(g, o, i, gr).permute(0, 2, 3, 1)   # [g, I, G, O]
         bias = None
         if l0.use_base_update:
-            bw = torch.stack([m.base_linear.weight for m in layers]).permute(0, 2, 1).unsqueeze(2)       # [g, I, 1, O]
+            bw = grouped.stack_params([m.base_linear.weight for m in layers]).permute(0, 2, 1).unsqueeze(2)       # [g, I, 1, O]
             w = torch.cat([w, bw], dim=2)
-            bias = torch.stack([m.base_linear.bias for m in layers])
+            bias = grouped.stack_params([m.base_linear.bias for m in layers])
         return w.reshape(g, -1, o), torch.stack([m.rbf.grid.detach() for m in layers]), bias
 
     def kan_u(self, x2d):
@@ -94,8 +94,8 @@ class FastKANLayer(nn.Module):
         M = x2d.shape[0]
         dh = layers[0].input_dim
         xhat = F.layer_norm(x2d.view(M, n_heads, dh), (dh,), None, None, layers[0].layernorm.eps)
-        gamma = torch.stack([l.layernorm.weight for l in layers]).view(1, 3, n_heads, dh)
-        beta = torch.stack([l.layernorm.bias for l in layers]).view(1, 3, n_heads, dh)
+        gamma = grouped.stack_params([l.layernorm.weight for l in layers]).view(1, 3, n_heads, dh)
+        beta = grouped.stack_params([l.layernorm.bias for l in layers]).view(1, 3, n_heads, dh)
         return torch.addcmul(beta, xhat.unsqueeze(1), gamma).reshape(M, 3 * n_heads * dh)
 
     def forward(self, x, time_benchmark=False):

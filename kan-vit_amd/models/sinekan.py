@@ -63,11 +63,11 @@ class SineKANLayer(torch.nn.Module):
     def kan_pack_grouped(layers):
         l0 = layers[0]
         g, gs = len(layers), l0.grid_size
-        a = torch.stack([m.amplitudes for m in layers])                      # [g, O, I, G]
+        a = grouped.stack_params([m.amplitudes for m in layers])                      # [g, O, I, G]
         w = a.permute(0, 2, 3, 1).reshape(g, l0.input_dim * gs, l0.output_dim)
-        bp = torch.cat([torch.stack([m.freq.reshape(gs) for m in layers]),
-                        torch.stack([m.phase.reshape(-1) for m in layers])], dim=1)
-        bias = torch.stack([m.bias.reshape(-1) for m in layers]) if l0.add_bias else None
+        bp = torch.cat([grouped.stack_params([m.freq.reshape(gs) for m in layers]),
+                        grouped.stack_params([m.phase.reshape(-1) for m in layers])], dim=1)
+        bias = grouped.stack_params([m.bias.reshape(-1) for m in layers]) if l0.add_bias else None
         return w, bp, bias
 
     def forward(self, x):
