@@ -39,6 +39,39 @@ __device__ __forceinline__ float kv_tanh(float x) {
     return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
 }
 
+// sin and cos together, |x| up to ~5e4 with <= 9e-8 absolute error (libm's float sin: 7e-8): k = rint(x * 2/pi), a
+// three-term Cody-Waite reduction r = x - k*pi/2 (exact products through fma), then the Cephes minimax polynomials on
+// [-pi/4, pi/4] and a quadrant swap.  ~20 VALU ops for both values; ocml's sinf + cosf (Payne-Hanek path included) are
+// several times that, and the Sine/Fourier layers evaluate one per (row, feature, grid point).
+__device__ __forceinline__ void kv_sincos(float x, float& s, float& c) {
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.371138828673793e-08f, r);
+    r = fmaf(k, 1.7763568394002505e-15f, r);
+    const int q = (int)k;
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const bool swap = (q & 1) != 0;
+    const float ss = swap ? cp : sp, cc = swap ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ float kv_sin(float x) {
+    float s, c;
+    kv_sincos(x, s, c);
+    return s;
+}
+__device__ __forceinline__ float kv_cos(float x) {
+    float s, c;
+    kv_sincos(x, s, c);
+    return c;
+}
+
 __device__ __forceinline__ float kv_silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float kv_dsilu(float x) {
     const float s = 1.0f / (1.0f + __expf(-x));
@@ -185,10 +218,10 @@ __device__ __forceinline__ void basis_fwd(const BasisArgs& b, float xv, float uv
     } else if constexpr (FAM == KV_SINE) {
         const float* fr = b.bp;
         const float* ph = b.bp + b.G + (long long)i * b.G;
-        for (int g = 0; g < b.G; ++g) dst[g * stride] = sinf(__fadd_rn(__fmul_rn(xv, fr[g]), ph[g]));
+        for (int g = 0; g < b.G; ++g) dst[g * stride] = kv_sin(__fadd_rn(__fmul_rn(xv, fr[g]), ph[g]));
     } else if constexpr (FAM == KV_FOURIER) {
         float s1, c1;
-        sincosf(xv, &s1, &c1);
+        kv_sincos(xv, s1, c1);
         float ck = c1, sk = s1;
         for (int k = 0; k < b.G; ++k) {
             dst[k * stride] = ck;
@@ -269,7 +302,7 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
         float acc = 0.0f;
         for (int g = 0; g < b.G; ++g) {
             const float f = fr[g];
-            const float c = cosf(__fadd_rn(__fmul_rn(xv, f), ph[g]));
+            const float c = kv_cos(__fadd_rn(__fmul_rn(xv, f), ph[g]));
             const float da = valid ? dA[g * stride] : 0.0f;
             acc += da * c * f;
             const float part = kv_wave_sum(da * c * xv);     // all 64 lanes take part (uniform trip count)
@@ -278,7 +311,7 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
         dx = acc;
     } else if constexpr (FAM == KV_FOURIER) {
         float s1, c1;
-        sincosf(xv, &s1, &c1);
+        kv_sincos(xv, s1, c1);
         float ck = c1, sk = s1, acc = 0.0f;
         for (int k = 0; k < b.G; ++k) {
             const float kf = (float)(k + 1);
@@ -291,6 +324,27 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
     }
 }
 
+
+// SINE input gradient with the frequency-gradient partial sums kept in registers (G <= KV_SINE_REG_G): the caller
+// wave-reduces dfq once per tile.  Same arithmetic as basis_bwd<KV_SINE>.
+constexpr int KV_SINE_REG_G = 32;
+__device__ __forceinline__ void basis_bwd_sine_reg(const BasisArgs& b, float xv, int i, const float* __restrict__ dA, int stride,
+                                                   float& dx, float (&dfq)[KV_SINE_REG_G]) {
+    const float* fr = b.bp;
+    const float* ph = b.bp + b.G + (long long)i * b.G;
+    float acc = 0.0f;
+#pragma unroll
+    for (int g = 0; g < KV_SINE_REG_G; ++g) {
+        if (g < b.G) {
+            const float f = fr[g];
+            const float c = kv_cos(__fadd_rn(__fmul_rn(xv, f), ph[g]));
+            const float da = dA[g * stride];
+            acc += da * c * f;
+            dfq[g] += da * c * xv;
+        }
+    }
+    dx = acc;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Generator form of the same bases: init() once per (row, feature), then next(j) for j = 0 .. GP-1 in order.  Used by
@@ -323,7 +377,7 @@ struct BasisGen {
             float dv[4];
             in = kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, false);     // uniform knots only (host-checked)
         } else if constexpr (FAM == KV_FOURIER) {
-            sincosf(xv, &s1, &c1);
+            kv_sincos(xv, s1, c1);
             ck = c1;
             sk = s1;
         }
@@ -348,7 +402,7 @@ struct BasisGen {
             const float d = (u - bp[j]) * inv_h;
             return __expf(-d * d);
         } else if constexpr (FAM == KV_SINE) {
-            return sinf(__fadd_rn(__fmul_rn(x, bp[j]), bp[G + (long long)i * G + j]));
+            return kv_sin(__fadd_rn(__fmul_rn(x, bp[j]), bp[G + (long long)i * G + j]));
         } else {   // FOURIER: cos(k x) for j < G, then sin(k x)
             if (j == 0) return c1;
             if (j == G) {
@@ -390,7 +444,7 @@ struct BasisDGen {
             float bv[4];
             in = kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, true);
         } else if constexpr (FAM == KV_FOURIER) {
-            sincosf(xv, &s1, &c1);
+            kv_sincos(xv, s1, c1);
             ck = c1;
             sk = s1;
         }

@@ -1517,6 +1517,30 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
         const float* us = u_s + (q & 1) * XS;
         float* dus = du_s + (q & 1) * XS;
         const int r = pt & (BM - 1);
+        if constexpr (SINE) {
+            if (a.G <= KV_SINE_REG_G) {
+                // d loss / d freq[g] = sum over (row, feature) of dA * cos(.) * x: per-lane partial sums in registers over
+                // the whole tile, ONE wave reduction per grid point at the end (not one per element)
+                float dfq[KV_SINE_REG_G];
+#pragma unroll
+                for (int g2 = 0; g2 < KV_SINE_REG_G; ++g2) dfq[g2] = 0.0f;
+                for (int il = pt >> 7; il < IC; il += 2) {
+                    if (ci * IC + il >= a.I) break;
+                    float dxv;
+                    basis_bwd_sine_reg(b, xs[r * ICP + il], ci * IC + il, dA_s + (il * GP) * AS + r, AS, dxv, dfq);
+                    dxs[r * ICP + il] += dxv;
+                }
+                float* dst = dfq_s + (p * 4 + pw) * a.G;
+#pragma unroll
+                for (int g2 = 0; g2 < KV_SINE_REG_G; ++g2) {
+                    if (g2 < a.G) {
+                        const float part = kv_wave_sum(dfq[g2]);
+                        if ((threadIdx.x & 63) == 0) dst[g2] += part;
+                    }
+                }
+                return;
+            }
+        }
         for (int il = pt >> 7; il < ((IC + 1) & ~1); il += 2) {   // uniform trip count (SINE wave-reduces)
             const bool valid = (il < IC) && (ci * IC + il < a.I);
             const int ilc = valid ? il : 0;
@@ -2646,7 +2670,10 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     const int fam = d->family;
     if (fam == KANVIT_LINEAR && p.gp == 1) p.nt = 6;
     else if (fam == KANVIT_CHEBY && p.gp == 5) p.nt = 3;
-    else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) p.nt = 1;
+    // BSPLINE (GP = 9 -> one column tile per wave): every column-tile wave re-evaluates the spline basis, and measured
+    // it loses to the LDS-tile kernel (2.46 vs 1.15 ms on the ViT-B q|k|v launch) -- opt-in only until that is fixed
+    else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 &&
+             getenv("KANVIT_REG_BW_BSPLINE")) p.nt = 1;
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 1;
     else return p;
     if (d->I % 32 || d->O % 32 || d->M < 256) return p;

@@ -14,5 +14,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT -o pmc_$C -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer "$@" > $OUT/pmc_$C.log 2>&1 || exit 1
   python3 $R/tools/summarize_prof.py pmc $OUT/pmc_${C}_counter_collection.csv $C > $OUT/pmc_$C.md
 done
+SUF=""; case " $* " in *" bf16 "*) SUF="_bf16";; esac
+python3 $R/tools/pmc_to_traffic.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv "$SUF" > $OUT/traffic.json
 rm -f $OUT/trace_kernel_trace.csv $OUT/pmc_*_counter_collection.csv
 ls -la $OUT
