@@ -325,6 +325,87 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// BasisGen with the per-lane constants hoisted: prepare() once per (lane, feature), then init()/next() per token touch no
+// memory.  The streaming weight-gradient kernel evaluates the basis inside a software-pipelined token loop whose body is
+// conditional, so the compiler cannot speculate the parameter loads (knots, centres, frequencies, phases) out of it; left
+// in the loop they put an L1 round trip on the critical path of every step.
+// ---------------------------------------------------------------------------------------------
+template <int FAM, int GP>
+struct BasisGenP {
+    static constexpr int NC0 = (FAM == KV_SINE || FAM == KV_RBF) ? GP : 1;
+    static constexpr int NC1 = (FAM == KV_SINE) ? GP : 1;
+    float c0[NC0], c1[NC1];
+    float g0, ih, inv_h;
+    int nkm1, G;
+    float x, u, t, p0, p1;
+    float bv[4];
+    int j0;
+    bool in;
+
+    __device__ __forceinline__ void prepare(const BasisArgs& b, int feat) {
+        G = b.G;
+        inv_h = b.inv_h;
+        if constexpr (FAM == KV_SINE) {
+#pragma unroll
+            for (int j = 0; j < GP; ++j) {
+                c0[j] = b.bp[j];
+                c1[j] = b.bp[b.G + (long long)feat * b.G + j];
+            }
+        } else if constexpr (FAM == KV_RBF) {
+#pragma unroll
+            for (int j = 0; j < GP; ++j) c0[j] = (j < b.G) ? b.bp[j] : 0.0f;
+        } else if constexpr (FAM == KV_BSPLINE) {       // uniform knots (host-checked)
+            g0 = b.bp[0];
+            nkm1 = b.nk - 1;
+            ih = __frcp_rn((b.bp[nkm1] - g0) / (float)nkm1);
+        }
+    }
+    __device__ __forceinline__ void init(float xv, float uv) {
+        x = xv;
+        u = uv;
+        if constexpr (FAM == KV_CHEBY) {
+            t = kv_tanh(xv);
+            p0 = 1.0f;
+            p1 = t;
+        } else if constexpr (FAM == KV_BSPLINE) {       // same arithmetic as kv_bspline_uniform
+            const float tt = (xv - g0) * ih;
+            const float fl = floorf(tt);
+            j0 = (int)fl;
+            in = (tt >= 0.0f) && (j0 < nkm1);
+            const float uu = tt - fl, u2 = uu * uu, u3 = u2 * uu, om = 1.0f - uu;
+            const float s6 = 1.0f / 6.0f;
+            bv[0] = om * om * om * s6;
+            bv[1] = (3.0f * u3 - 6.0f * u2 + 4.0f) * s6;
+            bv[2] = (-3.0f * u3 + 3.0f * u2 + 3.0f * uu + 1.0f) * s6;
+            bv[3] = u3 * s6;
+        }
+    }
+    __device__ __forceinline__ float next(int j) {
+        if constexpr (FAM == KV_LINEAR) {
+            return x;
+        } else if constexpr (FAM == KV_CHEBY) {
+            if (j == 0) return 1.0f;
+            if (j == 1) return t;
+            const float p2 = 2.0f * t * p1 - p0;
+            p0 = p1;
+            p1 = p2;
+            return p2;
+        } else if constexpr (FAM == KV_BSPLINE) {
+            if (j >= G) return kv_silu(x);
+            const int e = j - (j0 - 3);
+            const float v = e == 0 ? bv[0] : (e == 1 ? bv[1] : (e == 2 ? bv[2] : bv[3]));
+            return (in && e >= 0 && e < 4) ? v : 0.0f;
+        } else if constexpr (FAM == KV_RBF) {
+            if (j >= G) return kv_silu(x);
+            const float d = (u - c0[j < NC0 ? j : 0]) * inv_h;
+            return __expf(-d * d);
+        } else {   // SINE
+            return kv_sin(__fadd_rn(__fmul_rn(x, c0[j < NC0 ? j : 0]), c1[j < NC1 ? j : 0]));
+        }
+    }
+};
+
 // SINE input gradient with the frequency-gradient partial sums kept in registers (G <= KV_SINE_REG_G): the caller
 // wave-reduces dfq once per tile.  Same arithmetic as basis_bwd<KV_SINE>.
 constexpr int KV_SINE_REG_G = 32;
@@ -423,13 +504,14 @@ struct BasisGen {
 template <int FAM>
 struct BasisDGen {
     float x, u, t, sech2, u0, u1, c1, s1, ck, sk, inv_h;
+    float lastc;   // SINE: cos(x f_j + p_ij) of the last next() (the caller needs it for d loss / d freq)
     float dv[4];
-    int j0, G;
+    int j0, G, i;
     bool in;
     const float* bp;
 
     __device__ __forceinline__ void init(const BasisArgs& b, float xv, float uv, int feat) {
-        (void)feat;
+        i = feat;
         x = xv;
         u = uv;
         G = b.G;
@@ -469,6 +551,10 @@ struct BasisDGen {
             if (j >= G) return kv_dsilu(x);
             const float d = (u - bp[j]) * inv_h;
             return __expf(-d * d) * (-2.0f * d * inv_h);
+        } else if constexpr (FAM == KV_SINE) {      // d sin(x f + p)/dx = f cos(x f + p)
+            const float f = bp[j];
+            lastc = kv_cos(__fadd_rn(__fmul_rn(x, f), bp[G + (long long)i * G + j]));
+            return lastc * f;
         } else if constexpr (FAM == KV_FOURIER) {   // d cos(kx) = -k sin(kx) for j < G, d sin(kx) = k cos(kx) after
             if (j == G) {
                 ck = c1;

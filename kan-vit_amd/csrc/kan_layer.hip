@@ -531,7 +531,9 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_kernel(const LayerArgs a) {
 // The contraction index n is split per 32-column chunk as n = n0 + hf*16 + s so a lane consumes 16 CONSECUTIVE dY values.
 // 256 threads = 4 waves x 32 rows; LDS = two W^T chunk buffers [32 n][KCT+1]; one barrier per 32 dY columns.
 // SHARED: q, k, v of a head are summed in the accumulators (one chain rule per head); otherwise one chain rule per group.
-// Requirements (host-checked): GP compile time, I % (2*FPH) == 0, O % 32 == 0, 16-byte aligned rows, not SINE.
+// Requirements (host-checked): GP compile time, I % (2*FPH) == 0, O % 32 == 0, 16-byte aligned rows.
+// SINE (GP = 5): d loss / d freq is summed per lane over the features of a step, wave-reduced into per-wave LDS slots and
+// written as this row tile's partials to dparam (same protocol as the LDS-tile kernel).
 // =============================================================================================
 template <int FAM, int GP, int KT, bool SHARED>
 __global__ __launch_bounds__(256) void kan_bwd_input_reg_kernel(const LayerArgs a) {
@@ -552,6 +554,11 @@ __global__ __launch_bounds__(256) void kan_bwd_input_reg_kernel(const LayerArgs 
     const long long grow = m0 + (row_ok ? row : 0);
     float* W_s = smem;                            // [2][32][WS]
     constexpr int WSZ = 32 * WS;
+    constexpr bool SINE = (FAM == KV_SINE);
+    float* dfq_s = W_s + 2 * WSZ;                 // SINE: [nshare][4 waves][GP] partial d loss / d freq of this row tile
+    if constexpr (SINE) {
+        for (int j = tid; j < nshare * 4 * GP; j += 256) dfq_s[j] = 0.0f;
+    }
 
     const float* xrow = a.x + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     float* dxrow = a.dx + grow * a.ldx + (long long)gx * a.I + hf * FPH;
@@ -670,6 +677,11 @@ __global__ __launch_bounds__(256) void kan_bwd_input_reg_kernel(const LayerArgs 
 #pragma unroll
                 for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
             }
+            float dfq[SINE ? GP : 1];
+            if constexpr (SINE) {
+#pragma unroll
+                for (int g_ = 0; g_ < GP; ++g_) dfq[g_] = 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < FPH; ++j) {
                 BasisDGen<FAM> gen;
@@ -682,10 +694,18 @@ __global__ __launch_bounds__(256) void kan_bwd_input_reg_kernel(const LayerArgs 
                     const float v = acc[slot / 16][slot % 16];
                     if (RBF && g_ < GP - 1) usum += v * d;       // RBF: the last column is the silu base path (has_base)
                     else dsum += v * d;
+                    if constexpr (SINE) dfq[g_] += v * gen.lastc * xv[j];
                 }
                 if (RBF && !a.has_base) { usum += dsum; dsum = 0.0f; }
                 dxacc[j] += dsum;
                 if constexpr (RBF) duv[j] = usum;
+            }
+            if constexpr (SINE) {                 // one wave reduction per grid point and step; rows past M contribute nothing
+#pragma unroll
+                for (int g_ = 0; g_ < GP; ++g_) {
+                    const float part = kv_wave_sum(row_ok ? dfq[g_] : 0.0f);
+                    if (lane == 0) dfq_s[(p * 4 + wave) * GP + g_] += part;
+                }
             }
             if constexpr (RBF) {
                 if (a.du && row_ok) {
@@ -718,6 +738,14 @@ __global__ __launch_bounds__(256) void kan_bwd_input_reg_kernel(const LayerArgs 
         if (t + 1 < T) store_w((t + 1) & 1);
         __syncthreads();
         ci = cin; p = pn; cn = cnn;
+    }
+    if constexpr (SINE) {                         // combine the 4 waves in a fixed order (last loop barrier orders the adds)
+        for (int j = tid; j < nshare * GP; j += 256) {
+            const int pp = j / GP, gg = j - pp * GP;
+            const float* src = dfq_s + (pp * 4) * GP + gg;
+            const float v = ((src[0] + src[GP]) + src[2 * GP]) + src[3 * GP];
+            a.dparam[((long long)blockIdx.y * a.groups + (pp * a.xmod + gx)) * a.G + gg] = v;
+        }
     }
 }
 
@@ -1880,25 +1908,27 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_weight_kernel(const LayerArgs a)
 // the GP k-tiles.  The dY operand is a plain dword load (lane = output column).  Each wave accumulates a
 // [32 features x GP] x [NOT column tiles] block of dW in registers (GP*NOT*16 accumulators) over its slab of tokens;
 // operands are software-prefetched PD blocks ahead (one wave per SIMD: latency is hidden by the prefetch, not occupancy).
-// Work-group = 2 feature blocks x 2 column-tile sets, so x and dY are each fetched by two waves of the same CU.
+// Work-group = 4 consecutive wave units (feature block fastest), so neighbouring waves share dY (and x across tile sets).
 // fp32: v_mfma_f32_32x32x2f32, 2 tokens per step (lane half = token parity).  bf16 flag: v_mfma_f32_32x32x16_bf16, 16
 // tokens per step, lane half h owns tokens 8h..8h+7 of the step.  Rows beyond the slab end are clamped for x and zeroed
 // for dY.  Partials go to slab[blockIdx.y][g][k][o]; kan_slab_reduce_kernel sums them in order.
-// grid (basis groups, slabs, ceil(nfb/2)*ceil(nos/2)), 256 threads.
+// grid (ceil(units / 4), slabs), 256 threads = 4 wave units.
 // =============================================================================================
 template <int FAM, int GP, int NOT, bool BF>
 __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
-                                                                 int shared) {
+                                                                 int shared, int nbg) {
     constexpr bool RBF = (FAM == KV_RBF);
     constexpr int TS = BF ? 8 : 1;            // tokens per lane per step
     constexpr int UB = BF ? 1 : 4;            // steps per prefetch block
     constexpr int PD = BF ? 3 : 2;            // blocks in flight
     constexpr int NTOK = TS * UB;             // tokens per lane per block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
-    const int bg = blockIdx.x;
-    const int fb2 = (nfb + 1) >> 1;
-    const int fb = 2 * ((int)blockIdx.z % fb2) + (wave & 1), os = 2 * ((int)blockIdx.z / fb2) + (wave >> 1);
-    if (fb >= nfb || os >= nos) return;
+    // wave unit u = (basis group, column-tile set, feature block), feature block fastest: the 4 waves of a work-group are
+    // always 4 live units (a partly populated work-group would leave SIMDs idle: one wave fills a SIMD's register file,
+    // so the next work-group cannot start until ALL four SIMDs are free)
+    const int u = (int)blockIdx.x * 4 + wave;
+    if (u >= nfb * nos * nbg) return;
+    const int fb = u % nfb, os = (u / nfb) % nos, bg = u / (nfb * nos);
     const long long ms = (long long)blockIdx.y * a.rows_per_split;
     long long me = ms + a.rows_per_split;
     if (me > a.M) me = a.M;
@@ -1918,13 +1948,15 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
             const int p = tt / otpg;
             tg[i] = shared ? p * a.xmod + bg : bg;
             tcol[i] = (long long)tg[i] * a.O + (tt - p * otpg) * 32;
-        } else {
+        } else {            // past the last tile: recompute the first tile (no branch around the MFMAs), never stored
             tg[i] = -1;
-            tcol[i] = 0;
+            tcol[i] = (long long)(shared ? ((os * NOT) / otpg) * a.xmod + bg : bg) * a.O + ((os * NOT) % otpg) * 32;
         }
     }
-    const int g0 = shared ? bg : bg;   // basis parameters: identical for every group of a shared launch
+    const int g0 = bg;                 // basis parameters: identical for every group of a shared launch
     const BasisArgs b = make_basis(a, g0);
+    BasisGenP<FAM, GP> proto;          // knots / centres / frequencies / phases of this lane's feature, loaded once
+    proto.prepare(b, f);
 
     const float* xcol = a.x + (long long)gx * a.I + f;
     const float* ucol = RBF ? (a.u ? a.u + (long long)g0 * a.I + f : xcol) : xcol;
@@ -1979,23 +2011,23 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                 if constexpr (!BF) {
 #pragma unroll
                     for (int t = 0; t < NTOK; ++t) {
-                        BasisGen<FAM> gen;
-                        gen.init(b, cx[t], RBF ? cu[t] : 0.0f, f);
+                        BasisGenP<FAM, GP> gen = proto;
+                        gen.init(cx[t], RBF ? cu[t] : 0.0f);
 #pragma unroll
                         for (int j = 0; j < GP; ++j) {
                             const float av = gen.next(j);
 #pragma unroll
                             for (int i = 0; i < NOT; ++i)
-                                if (tg[i] >= 0) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
+                                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
                         }
                     }
                 } else {
                     unsigned af[GP][4];
 #pragma unroll
                     for (int ep = 0; ep < 4; ++ep) {
-                        BasisGen<FAM> g0_, g1_;
-                        g0_.init(b, cx[2 * ep], RBF ? cu[2 * ep] : 0.0f, f);
-                        g1_.init(b, cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f, f);
+                        BasisGenP<FAM, GP> g0_ = proto, g1_ = proto;
+                        g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
+                        g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
 #pragma unroll
                         for (int j = 0; j < GP; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
                     }
@@ -2012,7 +2044,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                         const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, a4);
 #pragma unroll
                         for (int i = 0; i < NOT; ++i)
-                            if (tg[i] >= 0) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[i], acc[j][i], 0, 0, 0);
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[i], acc[j][i], 0, 0, 0);
                     }
                 }
             }
@@ -2471,7 +2503,8 @@ int launch_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
         ((uintptr_t)a.dx & 15) || ((uintptr_t)a.dy & 15) || ((uintptr_t)a.w & 15))
         return 1;
     if ((long long)IC * GP * a.O >= (1LL << 30)) return 1;
-    const size_t lds = sizeof(float) * 2 * 32 * (32 * KT + 1);
+    const size_t lds = sizeof(float) * (2 * 32 * (32 * KT + 1) + (FAM == KV_SINE ? (size_t)nshare * 4 * GP : 0));
+    if (FAM == KV_SINE && !a.dparam) return 1;
     const bool shared = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare > 1;
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
     if (shared) {
@@ -2497,6 +2530,10 @@ int try_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
     }
     if constexpr (FAM == KV_RBF) { if (a.GP == 9 && a.has_base) return launch_bwd_input_reg<FAM, 9, 5>(a, st); }
     if constexpr (FAM == KV_FOURIER) { if (a.GP == 56) return launch_bwd_input_reg<FAM, 56, 7>(a, st); }
+    if constexpr (FAM == KV_SINE) {   // attention.py:140 builds the per-head sine mappings with grid_size = 4; 5 is the layer's default
+        if (a.GP == 4) return launch_bwd_input_reg<FAM, 4, 4>(a, st);
+        if (a.GP == 5) return launch_bwd_input_reg<FAM, 5, 5>(a, st);
+    }
     return 1;
 }
 
@@ -2673,8 +2710,9 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // BSPLINE (GP = 9 -> one column tile per wave): every column-tile wave re-evaluates the spline basis, and measured
     // it loses to the LDS-tile kernel (2.46 vs 1.15 ms on the ViT-B q|k|v launch) -- opt-in only until that is fixed
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 &&
-             getenv("KANVIT_REG_BW_BSPLINE")) p.nt = 1;
+             getenv("KANVIT_REG_BW_BSPLINE")) p.nt = 2;
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 1;
+    else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
     else return p;
     if (d->I % 32 || d->O % 32 || d->M < 256) return p;
     const int nshare = d->groups / d->x_group_mod;
@@ -2683,10 +2721,12 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     p.tiles_per_bg = (p.shared ? nshare : 1) * (d->O / 32);
     p.nfb = d->I / 32;
     p.nos = (p.tiles_per_bg + p.nt - 1) / p.nt;
-    const long long per = (long long)p.nbg * ((p.nfb + 1) / 2) * ((p.nos + 1) / 2);
+    // one live wave per SIMD (the accumulator block fills the register file): size the slab count so that the live waves
+    // (work-groups whose 2x2 wave grid is only partly populated retire their idle waves at once) cover the chip r times
+    const long long units = (long long)p.nbg * p.nfb * p.nos;
     long long r = 1;
-    while ((long long)N_CU * r < per) ++r;
-    long long S = (long long)N_CU * r / per;
+    while (4LL * N_CU * r < units) ++r;
+    long long S = 4LL * N_CU * r / units;
     const long long smax = d->M / 256;
     if (S > smax) S = smax;
     if (S < 1) S = 1;
@@ -2695,8 +2735,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     rps = (rps + 15) / 16 * 16;
     p.rows_per_slab = rps;
     p.slabs = (int)((d->M + rps - 1) / rps);
-    if ((long long)d->ldy * 1 >= (1LL << 40) || per * 1 > 65535LL * 65535LL) return p;
-    if (((p.nfb + 1) / 2) * ((p.nos + 1) / 2) > 65535) return p;
+    if (units > (1LL << 30)) return p;
     p.ws_bytes = p.slabs > 1 ? sizeof(float) * (size_t)p.slabs * d->groups * ((size_t)d->I * p.gp) * d->O : 0;
     p.ok = true;
     return p;
@@ -2704,11 +2743,12 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
 
 template <int FAM, int GP, int NOT>
 int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
-    dim3 grid((unsigned)p.nbg, (unsigned)p.slabs, (unsigned)(((p.nfb + 1) / 2) * ((p.nos + 1) / 2)));
+    const long long units = (long long)p.nbg * p.nfb * p.nos;
+    dim3 grid((unsigned)((units + 3) / 4), (unsigned)p.slabs, 1);
     if (bf)
-        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared);
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     else
-        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared);
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
     return 0;
 }
@@ -2717,8 +2757,10 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
     switch (family) {
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
         case KANVIT_CHEBY: return launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
-        case KANVIT_BSPLINE: return launch_bwd_weight_reg<KV_BSPLINE, 9, 1>(a, p, bf, st);
+        case KANVIT_BSPLINE: return launch_bwd_weight_reg<KV_BSPLINE, 9, 2>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 1>(a, p, bf, st);
+        case KANVIT_SINE:
+            return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE, 5, 2>(a, p, bf, st);
         default: return kv_fail(KANVIT_EINVAL, "internal: register weight-gradient dispatch");
     }
 }
