@@ -2711,7 +2711,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // it loses to the LDS-tile kernel (2.46 vs 1.15 ms on the ViT-B q|k|v launch) -- opt-in only until that is fixed
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 &&
              getenv("KANVIT_REG_BW_BSPLINE")) p.nt = 2;
-    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 1;
+    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 2;
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
     else return p;
     if (d->I % 32 || d->O % 32 || d->M < 256) return p;
@@ -2758,7 +2758,7 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
         case KANVIT_CHEBY: return launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
         case KANVIT_BSPLINE: return launch_bwd_weight_reg<KV_BSPLINE, 9, 2>(a, p, bf, st);
-        case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 1>(a, p, bf, st);
+        case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:
             return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE, 5, 2>(a, p, bf, st);
         default: return kv_fail(KANVIT_EINVAL, "internal: register weight-gradient dispatch");
