@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_kernel(const LayerArgs a) {
 // written as this row tile's partials to dparam (same protocol as the LDS-tile kernel).
 // =============================================================================================
 template <int FAM, int GP, int KT, bool SHARED>
-__global__ __launch_bounds__(256) void kan_bwd_input_reg_kernel(const LayerArgs a) {
+__global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2) void kan_bwd_input_reg_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KCT = 32 * KT;
     constexpr int WS = KCT + 1;
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(256) void kan_pack_w_bwd_reg_kernel(const float* __
 }
 
 template <int FAM, int GP, int KT, bool SHARED>
-__global__ __launch_bounds__(256) void kan_bwd_input_reg_bf16_kernel(const LayerArgs a) {
+__global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KCT = 32 * KT;
     constexpr int FPH = (16 * KT) / GP;
