@@ -18,6 +18,8 @@
 //                         (basis evaluation) and the MFMA A-operand reader
 //     W_s [KC][BN]        weight chunk, lane = output column
 #include "kan_basis.h"
+
+#include <type_traits>
 #include "kanvit_common.h"
 
 #include <stdlib.h>
@@ -1180,6 +1182,176 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
 }
 
 // =============================================================================================
+// forward, bf16, W-STATIONARY persistent form (when the whole bf16 image of the NSH groups' weights fits the LDS: the
+// per-head q|k|v launches).  The HBM roofline form of kan_fwd_reg_bf16_kernel:
+//   * a work-group loads its [all chunks][VS][2][NSH*BN][8] weight image into LDS ONCE and then walks row tiles
+//     (grid.y work-groups per column set, stride grid.y) -- no per-tile weight staging, no barrier after the first;
+//   * the product is flipped, Y^T = W^T . Phi^T: the weight fragment is the A operand (lane = output column: the same
+//     ds_read_b128 as before), the generated basis values are the B operand (lane = token).  The accumulator then holds
+//     4 consecutive output columns of the lane's OWN row per register quad -> float4 stores straight from registers,
+//     no staging tile;
+//   * x of the next (tile, chunk) is prefetched while the current chunk is contracted; 8 waves (2 per SIMD) of 32 rows.
+// =============================================================================================
+constexpr int KV_WS_THREADS = 512;   // 8 waves (12 measured slower: 66 row tiles over 21 work-groups per head quantise to 79 %)
+template <int FAM, int GP, int NT, int NSH, int ICH, int NCH>
+__global__ __launch_bounds__(KV_WS_THREADS, KV_WS_THREADS / 256) void kan_fwd_ws_bf16_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 32 * NT;
+    constexpr int WROW = NSH * BN;
+    constexpr int IC = 2 * ICH;
+    constexpr int VH = ICH * GP;
+    constexpr int VS = (VH + 7) / 8;
+    constexpr int NK = NCH * VS;                  // MFMA k-steps over the whole K
+    constexpr int NTT = NSH * NT;                 // column tiles per row
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr int ROWS = KV_WS_THREADS / 2;       // rows per work-group iteration (32 per wave)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int ntn = a.O / BN;
+    const int gs = blockIdx.x / ntn;
+    const int n0 = (blockIdx.x - gs * ntn) * BN;
+    const int nsets = a.groups / NSH;
+    unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [NK][2][WROW][8]
+    float* bias_s = reinterpret_cast<float*>(W_s + (size_t)NK * 2 * WROW * 8);   // [WROW] (zeros without a bias)
+
+    // ---- stage the whole weight image (and the bias of this column set) once
+    {
+        constexpr int nvec_g = NK * 2 * BN;       // 16-byte vectors per group
+        for (int p = 0; p < NSH; ++p) {
+            const int g = (NSH == 1) ? gs : p * nsets + gs;
+            const unsigned short* src = a.wb + ((long long)g * (NK * 2)) * a.O * 8;     // [NK*2][O][8]
+            for (int v = tid; v < nvec_g; v += KV_WS_THREADS) {
+                const int kr = v / BN, n = v - kr * BN;           // kr = (c*VS + ks)*2 + h
+                const u32x4 t = *reinterpret_cast<const u32x4*>(src + ((long long)kr * a.O + n0 + n) * 8);
+                *reinterpret_cast<u32x4*>(W_s + ((size_t)kr * WROW + p * BN + n) * 8) = t;
+            }
+            if (tid < BN) bias_s[p * BN + tid] = a.bias ? a.bias[(long long)g * a.O + n0 + tid] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const BasisArgs b = make_basis(a, gs);
+    const int xcol = (NSH == 1 ? gs % a.xmod : gs) * a.I;
+    const long long ntiles = (a.M + ROWS - 1) / ROWS;
+    const bool has_bias = a.bias != nullptr;
+
+    // Per row tile: (1) the basis fragments of the whole K are generated once into registers (NK bf16x8 values);
+    // (2) x of the NEXT tile is requested into the now dead x registers -- a full tile of MFMA work to land; (3) the column
+    // tiles are contracted TWO at a time over the whole K (weight fragments double-buffered in registers, one k-step ahead)
+    // and stored as soon as their pair is done, so stores drain under the MFMAs of the next pair.
+    float xcur[NCH][ICH], ucur[RBF ? NCH : 1][RBF ? ICH : 1];
+    auto load_tile_x = [&](long long tile) {
+        long long r = tile * ROWS + wave * 32 + l31;
+        if (r > a.M - 1) r = a.M - 1;
+        const float* xrow = a.x + r * a.ldx + xcol + hf * ICH;
+        const float* urow = (RBF && a.u) ? a.u + r * a.ldu + (long long)gs * a.I + hf * ICH : xrow;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if constexpr (ICH % 4 == 0) {
+#pragma unroll
+                for (int j4 = 0; j4 < ICH / 4; ++j4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + c * IC + 4 * j4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xcur[c][4 * j4 + e] = v[e];
+                    if constexpr (RBF) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(urow + c * IC + 4 * j4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ucur[c][4 * j4 + e] = w4[e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < ICH; ++e) {
+                    xcur[c][e] = xrow[c * IC + e];
+                    if constexpr (RBF) ucur[c][e] = urow[c * IC + e];
+                }
+            }
+        }
+    };
+
+    // The row-tile body exists twice: FULL tiles store unconditionally (a store under a branch makes the compiler's
+    // waitcnt bookkeeping pessimistic: later waits become vmcnt(0) and also wait for every store to retire).
+    auto do_tile = [&](long long tile, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        bf16x8_t phi[NK];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            BasisGen<FAM> gen;
+#pragma unroll
+            for (int ks = 0; ks < VS; ++ks) {
+                float av[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int vi = ks * 8 + e;                        // compile-time after unrolling
+                    const int j = vi / GP, g = vi - j * GP;
+                    if (vi < VH) {
+                        if (g == 0) gen.init(b, xcur[c][j], RBF ? ucur[RBF ? c : 0][RBF ? j : 0] : 0.0f, c * IC + hf * ICH + j);
+                        av[e] = gen.next(g);
+                    } else {
+                        av[e] = 0.0f;
+                    }
+                }
+                const u32x4 au = {kv_pack_bf16(av[0], av[1]), kv_pack_bf16(av[2], av[3]), kv_pack_bf16(av[4], av[5]),
+                                  kv_pack_bf16(av[6], av[7])};
+                phi[c * VS + ks] = __builtin_bit_cast(bf16x8_t, au);
+            }
+        }
+        if (tile + gridDim.y < ntiles) load_tile_x(tile + gridDim.y);
+
+        const long long r = tile * ROWS + wave * 32 + l31;
+        const bool st_ok = FULL || (r < a.M);
+        const unsigned short* wp = W_s + ((size_t)hf * WROW + l31) * 8;
+#pragma unroll 1
+        for (int t0 = 0; t0 < NTT; t0 += 2) {     // a real loop: unrolled, the scheduler hoists every ds_read of every pair and spills
+            constexpr bool PAIR = true;
+            const bool two = t0 + 1 < NTT;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc0[q] = 0.0f;
+                acc1[q] = 0.0f;
+            }
+            bf16x8_t w0[2], w1[2];
+            w0[0] = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)0 * WROW + t0 * 32) * 8);
+            w1[0] = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)0 * WROW + (two ? t0 + 1 : t0) * 32) * 8);
+#pragma unroll
+            for (int s2 = 0; s2 < NK; ++s2) {
+                if (s2 + 1 < NK) {
+                    w0[(s2 + 1) & 1] = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)(2 * (s2 + 1)) * WROW + t0 * 32) * 8);
+                    w1[(s2 + 1) & 1] = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)(2 * (s2 + 1)) * WROW + (two ? t0 + 1 : t0) * 32) * 8);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s2 & 1], phi[s2], acc0, 0, 0, 0);     // Y^T tile: rows = columns of y
+                if (PAIR && two) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s2 & 1], phi[s2], acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);            // keep the one-step-ahead fragment prefetch, no further hoisting
+            }
+            // accumulator registers 4q..4q+3 of a tile are y[row][.. + 8q + 4hf + 0..3] of this lane's row
+            if (st_ok) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = t0 + tt;
+                    if (t < NTT) {
+                        const int p = t / NT, nt = t - p * NT;
+                        const int g = (NSH == 1) ? gs : p * nsets + gs;
+                        float* yp = a.y + r * a.ldy + (long long)g * a.O + n0 + nt * 32 + 4 * hf;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = tt == 0 ? f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]}
+                                              : f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+                            if (has_bias) v += *reinterpret_cast<const f32x4*>(bias_s + t * 32 + 8 * q + 4 * hf);
+                            *reinterpret_cast<f32x4*>(yp + 8 * q) = v;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    const long long nfull = a.M / ROWS;           // tiles with all 256 rows present
+    long long tile = blockIdx.y;
+    if (tile < ntiles) load_tile_x(tile);
+    for (; tile < nfull; tile += gridDim.y) do_tile(tile, std::true_type{});
+    if (tile < ntiles) do_tile(tile, std::false_type{});
+}
+
+// =============================================================================================
 // backward w.r.t. the input, register form on the bf16 matrix cores.  Same slot <-> (feature, basis) permutation and
 // in-register chain rule as kan_bwd_input_reg_kernel; the contraction over the dY columns uses v_mfma_f32_32x32x16_bf16:
 // k-step ks covers 16 columns, lane half h the 8 columns 16*ks + 8*h .. +7 -- the B fragment is 8 consecutive dY values
@@ -2229,6 +2401,26 @@ FwdRegBf16Plan plan_fwd_reg_bf16(const kanvit_layer_desc* d) {
 
 template <int FAM, int GP, int NT, int NSH, int ICH>
 int launch_fwd_reg_bf16(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t st) {
+    // W-stationary persistent form when the whole weight image of a column set fits the LDS and there are enough row tiles
+    // (instantiated for I = 64 per group: 4 chunks of 16 features -- the per-head q|k|v launches of ViT-B/S)
+    if constexpr (ICH == 8 && (FAM == KV_LINEAR || FAM == KV_CHEBY)) {     // the families whose basis fragments fit the register file
+        const size_t wlds = (size_t)p.nch * p.vs * 2 * 32 * NT * NSH * 16 + sizeof(float) * 32 * NT * NSH;
+        const int gx = (a.groups / NSH) * (a.O / (32 * NT));
+        if (wlds <= 150 * 1024 && p.nch == 4 && a.M >= 4096 && gx <= N_CU && !((uintptr_t)a.y & 15) && !getenv("KANVIT_NO_WS")) {
+            static bool ws_attr_done = false;
+            if (!ws_attr_done) {
+                KV_HIP_CHECK(kv_allow_lds((kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>), 160 * 1024));
+                ws_attr_done = true;
+            }
+            const long long ntiles = (a.M + KV_WS_THREADS / 2 - 1) / (KV_WS_THREADS / 2);
+            long long py = N_CU / gx;             // one work-group per CU (the image fills the LDS)
+            if (py > ntiles) py = ntiles;
+            if (py < 1) py = 1;
+            hipLaunchKernelGGL((kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>), dim3((unsigned)gx, (unsigned)py, 1), dim3(KV_WS_THREADS), wlds, st, a);
+            KV_LAUNCH_CHECK("kan_fwd_ws_bf16_kernel");
+            return 0;
+        }
+    }
     static bool attr_done = false;
     if (!attr_done) {
         KV_HIP_CHECK(kv_allow_lds((kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>), 160 * 1024));
