@@ -99,6 +99,44 @@ def cpu_baseline(model, wl, target_s=15.0):
                       f"per-sample x per-head loop, after a 1-image warm-up step ({t1:.2f} s)"}
 
 
+def roofline_report(kern, steps, workload, batch):
+    """Per-op table + the roofline object of the dominant KAN op from the kernel timer's summary."""
+    res = {}
+    kernels = {}
+    for tag, r in kern.items():
+        tf = r["flops"] / (r["avg_ms"] * 1e-3) / 1e12
+        gb = r["bytes"] / (r["avg_ms"] * 1e-3) / 1e9
+        kernels[tag] = {"launches_per_step": r["launches"] / steps, "avg_ms": round(r["avg_ms"], 4),
+                        "ms_per_step": round(r["total_ms"] / steps, 3), "TFLOP/s": round(tf, 2),
+                        "GB/s": round(gb, 1), "alg_flops": r["flops"], "alg_bytes": r["bytes"]}
+    if not kernels:
+        return res
+    dom = max((t for t in kernels if t.startswith(("qkv", "layer"))), key=lambda t: kernels[t]["ms_per_step"])
+    k = kernels[dom]
+    ai = k["alg_flops"] / k["alg_bytes"]
+    mfma_peak = PEAK_BF16_MFMA_TFLOPS if dom.endswith("_bf16") else PEAK_FP32_MFMA_TFLOPS
+    mfma_bound = ai > mfma_peak * 1e3 / PEAK_HBM_GBS                   # ridge: 19.7 flop/B fp32 pipe, 312 bf16 pipe
+    if mfma_bound:
+        roof = {"bound": "mfma", "achieved": k["TFLOP/s"], "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": round(k["TFLOP/s"] / mfma_peak, 4), "traffic": None}
+    else:
+        roof = {"bound": "hbm", "achieved": k["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(k["GB/s"] / PEAK_HBM_GBS, 4), "traffic": None}
+    try:      # HBM bytes per launch from the committed PMC pass, when it was taken on this very workload
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        rec = pmc["kernels"].get(dom)
+        if pmc["workload"] == workload and pmc["per_gpu_batch"] == batch and rec and rec["write_kib"] is not None:
+            roof["traffic"] = (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024
+    except Exception:
+        pass
+    roof.update({"kernel": dom, "avg_launch_ms": k["avg_ms"], "arith_intensity_flop_per_byte": round(ai, 1),
+                 "hbm_GB/s": k["GB/s"], "hbm_frac": round(k["GB/s"] / PEAK_HBM_GBS, 4)})
+    res["roofline"] = roof
+    res["kernels"] = kernels
+    res["custom_kernel_ms_per_step"] = round(sum(v["ms_per_step"] for v in kernels.values()), 3)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +146,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary bf16-autocast measurement of the default run")
     ap.add_argument("--bucket-mib", type=float, default=64.0)
     ap.add_argument("--amp", choices=["off", "bf16"], default="off",
                     help="bf16 autocast for the stock dense ops (FF GEMMs); the kanvit kernels stay fp32 at their boundary")
@@ -151,8 +190,10 @@ def main():
     x = torch.randn(wl["batch"], *wl["chw"], device=dev, generator=g)
     y = torch.randint(0, wl["out_d"], (wl["batch"],), device=dev, generator=g)
 
+    amp_on = [args.amp == "bf16"]
+
     def step():
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.amp == "bf16"):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp_on[0]):
             loss = crit(model(x), y)
         if reducer is not None:
             reducer.zero_grad()
@@ -232,37 +273,30 @@ def main():
                        "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],
                        "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3)", "hip_graph": bool(use_graph), "loss_after": round(final_loss, 4)},
         }
-        kernels = {}
-        for tag, r in kern.items():
-            tf = r["flops"] / (r["avg_ms"] * 1e-3) / 1e12
-            gb = r["bytes"] / (r["avg_ms"] * 1e-3) / 1e9
-            kernels[tag] = {"launches_per_step": r["launches"] / args.steps, "avg_ms": round(r["avg_ms"], 4),
-                            "ms_per_step": round(r["total_ms"] / args.steps, 3), "TFLOP/s": round(tf, 2),
-                            "GB/s": round(gb, 1), "alg_flops": r["flops"], "alg_bytes": r["bytes"]}
-        if kernels:
-            dom = max((t for t in kernels if t.startswith(("qkv", "layer"))), key=lambda t: kernels[t]["ms_per_step"])
-            k = kernels[dom]
-            ai = k["alg_flops"] / k["alg_bytes"]
-            mfma_peak = PEAK_BF16_MFMA_TFLOPS if dom.endswith("_bf16") else PEAK_FP32_MFMA_TFLOPS
-            mfma_bound = ai > mfma_peak * 1e3 / PEAK_HBM_GBS                   # ridge: 19.7 flop/B fp32 pipe, 312 bf16 pipe
-            if mfma_bound:
-                out["roofline"] = {"bound": "mfma", "achieved": k["TFLOP/s"], "peak": mfma_peak,
-                                   "unit": "TFLOP/s", "frac": round(k["TFLOP/s"] / mfma_peak, 4),
-                                   "traffic": None}
-            else:
-                out["roofline"] = {"bound": "hbm", "achieved": k["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": round(k["GB/s"] / PEAK_HBM_GBS, 4), "traffic": None}
-            try:      # HBM bytes per launch from the committed PMC pass, when it was taken on this very workload
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                rec = pmc["kernels"].get(dom)
-                if pmc["workload"] == args.workload and pmc["per_gpu_batch"] == wl["batch"] and rec and rec["write_kib"] is not None:
-                    out["roofline"]["traffic"] = (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024
-            except Exception:
-                pass
-            out["roofline"].update({"kernel": dom, "avg_launch_ms": k["avg_ms"], "arith_intensity_flop_per_byte": round(ai, 1),
-                                    "hbm_GB/s": k["GB/s"], "hbm_frac": round(k["GB/s"] / PEAK_HBM_GBS, 4)})
-            out["kernels"] = kernels
-            out["custom_kernel_ms_per_step"] = round(sum(v["ms_per_step"] for v in kernels.values()), 3)
+        out.update(roofline_report(kern, args.steps, args.workload, wl["batch"]))
+        if world == 1 and args.amp == "off" and not use_graph and not force_dp and not args.no_amp_leg:
+            # Secondary measurement, same run: the same step with the stock GEMMs under bf16 autocast and the kanvit kernels on
+            # the bf16 matrix cores (BASELINE configs[2]/[4] name bf16 for the 224x224 streams).  `value` above is the fp32 path.
+            amp_on[0] = True
+            for _ in range(2):
+                step()
+            if not args.no_kernel_timer:
+                ops.timer = ops.KernelTimer()
+            asteps = max(3, args.steps // 2)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(asteps):
+                aloss = step()
+            fence()
+            adt = time.perf_counter() - t0
+            akern = ops.timer.summary() if ops.timer is not None else {}
+            ops.timer = None
+            amp_on[0] = False
+            leg = {"value": round(wl["batch"] * asteps / adt, 2), "unit": "images/s", "steps": asteps, "warmup": 2,
+                   "ms_per_step": round(1e3 * adt / asteps, 3), "dtype": "bf16 autocast (stock GEMMs) + kanvit kernels on bf16 MFMA, f32 I/O and accumulate",
+                   "loss_after": round(float(aloss.detach()), 4)}
+            leg.update(roofline_report(akern, asteps, args.workload, wl["batch"]))
+            out["amp_bf16"] = leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, wl)
         print(json.dumps(out), flush=True)
