@@ -74,7 +74,8 @@ def oracle_run(layer, x):
     return y.detach(), xd.grad, {k: v.grad for k, v in params.items() if v.grad is not None}
 
 
-SHAPES = [(1, 2, 1), (7, 5, 3), (127, 16, 64), (129, 64, 64), (1000, 33, 70), (300, 192, 64), (257, 8, 8), (513, 48, 200)]
+SHAPES = [(1, 2, 1), (7, 5, 3), (127, 16, 64), (129, 64, 64), (1000, 33, 70), (300, 192, 64), (257, 8, 8), (513, 48, 200),
+          (1100, 64, 64)]      # the last one: several ragged token slabs in the streaming weight-gradient kernel
 
 
 @pytest.mark.parametrize("fam", FAMS)
@@ -184,6 +185,28 @@ def test_bf16_mfma_gradients_close_to_fp32(fam, dh):
     for a, b in zip(grads(True), grads(False)):
         if float(b.abs().max()) > 1e-3:
             assert float((a - b).abs().max()) / float(b.abs().max()) < 3e-2, fam
+
+
+@pytest.mark.parametrize("fam", ["vanilla", "cheby"])
+def test_bf16_weight_stationary_forward_matches_tile_kernel(fam, monkeypatch):
+    """M >= 4096 rows switches the bf16 q|k|v forward to the persistent W-stationary kernel (weights resident in LDS,
+    flipped product, stores from accumulators).  Same bf16 operand rounding as the per-tile kernel, so the two must agree
+    to fp32 accumulation-order noise; a ragged last row tile (M % 256 != 0) and the bias path (vanilla) are included."""
+    from attention import MSA
+    from kanvit import grouped
+    torch.manual_seed(11)
+    msa = MSA(256, 4, type=fam).to(DEV)
+    x = torch.randn(4096 + 129, 256, device=DEV)
+    exact = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ws = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+        monkeypatch.setenv("KANVIT_NO_WS", "1")
+        tile = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+        monkeypatch.delenv("KANVIT_NO_WS")
+    scale = float(exact.abs().max())
+    assert float((ws - tile).abs().max()) / scale < 1e-5, fam
+    err = float((ws - exact).abs().max()) / scale
+    assert 0 < err < 2e-2, (fam, err)
 
 
 def test_bspline_non_uniform_or_differing_grids_take_the_general_path():
