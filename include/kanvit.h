@@ -151,6 +151,21 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
                     const float* o, const float* lse, const float* d_o,
                     float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- residual add + LayerNorm (the TransformerBlock assembly around the KAN / attention kernels) -------------------
+ * Replaces the `x + ...` adds and the nn.LayerNorm calls of model.py:31-37 (TransformerBlock.forward) and their autograd
+ * backward, two to four separate passes over [M, D] each in the reference, by one pass forward and one backward.
+ *   forward : s = x + delta (delta may be NULL);  y = (s - mean) * rstd * gamma + beta  (biased variance, eps inside the
+ *             square root: torch.nn.LayerNorm).  Writes y[M, D], mean[M], rstd[M] and, if xsum != NULL, s to xsum[M, D].
+ *   backward: dx = LayerNorm backward of dy w.r.t. s, plus dres[M, D] if not NULL (the gradient that arrives on the
+ *             residual stream); dgamma[D], dbeta[D] are fully written.  `xsum` is the s of the forward.
+ * Rows are contiguous (row stride D), D % 4 == 0, 4 <= D <= 1024, pointers 16-byte aligned.                        */
+int kanvit_addln_fwd(int64_t M, int D, float eps, const float* x, const float* delta, const float* gamma, const float* beta,
+                     float* xsum, float* y, float* mean, float* rstd, void* stream);
+size_t kanvit_addln_bwd_workspace(int64_t M, int D);
+int kanvit_addln_bwd(int64_t M, int D, const float* xsum, const float* gamma, const float* mean, const float* rstd,
+                     const float* dy, const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* ---- per-family named entry points (SURVEY.md section 8b naming) ----------------------------
  * kanvit_<family>_{fwd,bwd_input,bwd_weight} are kanvit_layer_* with d->family checked;
  * kanvit_<family>_qkv_* additionally require groups == 3 * x_group_mod (one launch for all

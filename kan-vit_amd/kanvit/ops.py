@@ -329,3 +329,60 @@ def attention_packed(qkv: torch.Tensor, causal: bool = False, scale: Optional[fl
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False,
               scale: Optional[float] = None) -> torch.Tensor:
     return _AttnFn.apply(q, k, v, causal, q.shape[-1] ** -0.5 if scale is None else scale, _autocast_flags())
+
+
+# ------------------------------------------------------------------------------------------------
+# residual add + LayerNorm (TransformerBlock assembly, reference model.py:31-37)
+# ------------------------------------------------------------------------------------------------
+class _AddLayerNormFn(torch.autograd.Function):
+    """(x, delta | None, gamma, beta) -> (s = x + delta, LayerNorm(s)) in one pass; backward in one pass + a tiny reduce."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, delta, gamma, beta, eps):
+        _require_gpu_f32("x", x)
+        _require_gpu_f32("delta", delta)
+        L = _lib.lib()
+        D = x.shape[-1]
+        x2 = x.contiguous().view(-1, D)
+        d2 = None if delta is None else delta.contiguous().view(-1, D)
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        s = torch.empty_like(x2) if d2 is not None else x2
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        g, b = gamma.contiguous(), beta.contiguous()
+        check(L.kanvit_addln_fwd(M, D, float(eps), _ptr(x2), _ptr(d2), _ptr(g), _ptr(b), _ptr(s) if d2 is not None else None,
+                                 _ptr(y), _ptr(mean), _ptr(rstd), _stream()), "kanvit_addln_fwd")
+        ctx.save_for_backward(s, g, mean, rstd)
+        ctx.has_delta = d2 is not None
+        ctx.shape = x.shape
+        return s.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gs, gy):
+        s, g, mean, rstd = ctx.saved_tensors
+        L = _lib.lib()
+        M, D = s.shape
+        gy2 = gy.contiguous().view(M, D).float() if gy is not None else torch.zeros_like(s)
+        gs2 = None if gs is None else gs.contiguous().view(M, D).float()
+        dx = torch.empty_like(s)
+        dg = torch.empty(D, device=s.device, dtype=torch.float32)
+        db = torch.empty(D, device=s.device, dtype=torch.float32)
+        nbytes = int(L.kanvit_addln_bwd_workspace(M, D))
+        ws = _workspace(nbytes, s.device)
+        check(L.kanvit_addln_bwd(M, D, _ptr(s), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(gy2), _ptr(gs2), _ptr(dx), _ptr(dg), _ptr(db),
+                                 _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_addln_bwd")
+        dx = dx.view(ctx.shape)
+        return dx, (dx if ctx.has_delta else None), dg, db, None
+
+
+def add_layernorm(x: torch.Tensor, delta: Optional[torch.Tensor], norm: torch.nn.LayerNorm):
+    """(x + delta, norm(x + delta)) -- delta None gives (x, norm(x)).  Shapes the kernel does not cover (last dim not a
+    multiple of 4 or > 1024, non-affine norms) take the stock ops; like every kanvit op it needs CUDA tensors."""
+    D = x.shape[-1]
+    if norm.weight is None or norm.bias is None or len(norm.normalized_shape) != 1 or D % 4 or D > 1024 or D < 4:
+        s = x if delta is None else x + delta
+        return s, norm(s)
+    return _AddLayerNormFn.apply(x, delta, norm.weight, norm.bias, norm.eps)

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from attention import MSA, FlashAttention
 from kanvit.dense import dense
+from kanvit.ops import add_layernorm
 from models.cheby import ChebyKANLayer
 from models.effkan import KANLinear
 from models.fastkan import FastKANLayer
@@ -28,15 +29,25 @@ class TransformerBlock(nn.Module):
                                 nn.Linear(feedforward_dim, d_model))
 
     def forward(self, x):
-        x = x + self.attn(self.norm1(x))
+        x, f = self.run(x, None)
+        return x + f
+
+    def run(self, x, pending):
+        """The block with its residual adds fused into the LayerNorms (kanvit.ops.add_layernorm: one pass instead of an
+        add kernel + a LayerNorm kernel forward, one pass instead of three + an add backward).  `pending` is the previous
+        block's feed-forward output that has not been added to the stream yet (None for the first block); returns
+        (stream after the attention add, this block's feed-forward output) -- same arithmetic as model.py:31-37:
+            x = x + MSA(LN1(x));  x = x + FF(LN2(x))."""
+        x, h1 = add_layernorm(x, pending, self.norm1)
+        x, h2 = add_layernorm(x, self.attn(h1), self.norm2)
         # Same three ops as self.ff (Linear -> ReLU(inplace) -> Linear, model.py:25-29), applied to the 2-D
         # (B*N, d) tensor: nn.Linear on 3-D input returns a VIEW, and an in-place ReLU on a view makes autograd
         # insert CopySlices (two full [B*N, 4d] copies per block in backward: 12 ms/step at ViT-B, B=128).
         # The two Linears go through kanvit.dense: stock GEMMs, but with the weight gradient split over tokens
         # (the unsplit library kernel fills 36 of 256 CUs: 2.2 ms -> 0.83 ms per call).
         b, n, d = x.shape
-        h = torch.relu_(dense(self.norm2(x).reshape(b * n, d), self.ff[0]))
-        return x + dense(h, self.ff[2]).view(b, n, d)
+        h = torch.relu_(dense(h2.reshape(b * n, d), self.ff[0]))
+        return x, dense(h, self.ff[2]).view(b, n, d)
 
 
 def _patch_embedding(kind, in_dim, d):
@@ -107,6 +118,14 @@ class VisionTransformer(nn.Module):
             tokens = self.linear_mapper(patches).reshape(b, p, self.d_hidden)
         cls = self.v_class.unsqueeze(0).expand(b, -1, -1)
         out = torch.cat((cls, tokens), dim=1) + self.pos_embeddings[: p + 1]
+        pending = None
         for blk in self.blocks:
-            out = blk(out)
-        return self.mlp_head(out[:, 0])
+            if isinstance(blk, TransformerBlock):
+                out, pending = blk.run(out, pending)
+            else:                                     # 'flash-attn' models stack bare FlashAttention modules (model.py:113-117)
+                out = blk(out)
+        if pending is not None:
+            out = out[:, 0] + pending[:, 0]       # only the class token feeds the head (model.py:166-169)
+        else:
+            out = out[:, 0]
+        return self.mlp_head(out)
