@@ -61,7 +61,8 @@ def main(args):
                               n_heads=args.n_heads, out_d=args.out_d, type=args.model_type).to(device)
     kdp.broadcast_parameters(model)
     criterion = torch.nn.CrossEntropyLoss()
-    optimizer = Adam(model.parameters(), lr=args.learning_rate)
+    # fused=True on the GPU: same update rule, one multi-tensor kernel per parameter chunk instead of ~8 per step
+    optimizer = Adam(model.parameters(), lr=args.learning_rate, fused=(device.type == "cuda"))
     reducer = kdp.GradReducer(model.parameters()) if world > 1 else None
     metrics_file = setup_logging(args.log_dir) if rank == 0 else None
     logging.info(f"Using device: {device} ({torch.cuda.get_device_name(device)}), world {world}")

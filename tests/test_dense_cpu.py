@@ -48,3 +48,23 @@ def test_split_path_taken_and_deterministic():
         D.dense(x, lin).square().sum().backward()
         outs.append(lin.weight.grad.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("bias", [True, False])
+def test_dense_relu_matches_linear_relu(bias):
+    """relu=True is Linear -> ReLU (reference model.py:25-29), with the mask applied to the gradient inside the op."""
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(24, 40, bias=bias).double()
+    x = torch.randn(1536, 24, dtype=torch.double, requires_grad=True)
+    dy = torch.randn(1536, 40, dtype=torch.double)
+    y = D.dense(x, lin, relu=True)
+    y.backward(dy)
+    got = [y.detach().clone(), x.grad.clone(), lin.weight.grad.clone()] + ([lin.bias.grad.clone()] if bias else [])
+    x.grad = None
+    lin.zero_grad()
+    y2 = torch.relu(lin(x))
+    y2.backward(dy)
+    want = [y2.detach(), x.grad, lin.weight.grad] + ([lin.bias.grad] if bias else [])
+    assert torch.equal(got[0], want[0])
+    for g, w in zip(got[1:], want[1:]):
+        assert float((g - w).abs().max()) <= 1e-11 * (1 + float(w.abs().max()))
