@@ -146,7 +146,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary bf16-autocast measurement of the default run")
+    ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary measurements (bf16 autocast, bf16x3 feed-forward) of the default run")
+    ap.add_argument("--ff", choices=["fp32", "bf16x3"], default="fp32",
+                    help="feed-forward GEMMs: stock fp32 (default, the parity path) or three-term bf16 split products (~5e-6 relative)")
     ap.add_argument("--bucket-mib", type=float, default=64.0)
     ap.add_argument("--amp", choices=["off", "bf16"], default="off",
                     help="bf16 autocast for the stock dense ops (FF GEMMs); the kanvit kernels stay fp32 at their boundary")
@@ -171,9 +173,11 @@ def main():
             dist.all_reduce(torch.zeros(1, device=dev))          # forces communicator creation (and its banner) now
             torch.cuda.synchronize()
 
+    from kanvit import dense as kdense
     from kanvit import dp as kdp
     from kanvit import ops
     from model import VisionTransformer
+    kdense.FF_MODE = args.ff
 
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -268,7 +272,8 @@ def main():
             "value": round(world * wl["batch"] * args.steps / dt, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.amp == "off" else "bf16 autocast (stock GEMMs) + f32 kanvit kernels", "data": "synthetic",
+            "dtype": ("f32" if args.ff == "fp32" else "f32 (feed-forward GEMMs as three-term bf16 split products, f32 accumulate)") if args.amp == "off"
+                     else "bf16 autocast (stock GEMMs) + f32 kanvit kernels", "data": "synthetic",
             "config": {"workload": args.workload, "model_type": wl["type"], "image": list(wl["chw"]),
                        "n_patches": wl["n_patches"], "n_blocks": wl["n_blocks"], "d_hidden": wl["d"],
                        "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],
@@ -298,6 +303,24 @@ def main():
                    "loss_after": round(float(aloss.detach()), 4)}
             leg.update(roofline_report(akern, asteps, args.workload, wl["batch"]))
             out["amp_bf16"] = leg
+            if args.ff == "fp32":
+                # Third measurement, same run: fp32 everywhere except that the feed-forward GEMMs are formed as three-term
+                # bf16 split products on the bf16 matrix cores (kanvit/dense.py; ~5e-6 relative, inside the 1e-4 parity budget
+                # but not bit-faithful fp32 products, hence not the headline).
+                kdense.FF_MODE = "bf16x3"
+                for _ in range(2):
+                    step()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(asteps):
+                    sloss = step()
+                fence()
+                sdt = time.perf_counter() - t0
+                kdense.FF_MODE = "fp32"
+                out["ff_bf16x3"] = {"value": round(wl["batch"] * asteps / sdt, 2), "unit": "images/s", "steps": asteps, "warmup": 2,
+                                    "ms_per_step": round(1e3 * sdt / asteps, 3),
+                                    "dtype": "f32 kanvit kernels + feed-forward GEMMs as three-term bf16 split products (f32 accumulate)",
+                                    "loss_after": round(float(sloss.detach()), 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, wl)
         print(json.dumps(out), flush=True)

@@ -166,6 +166,14 @@ int kanvit_addln_bwd(int64_t M, int D, const float* xsum, const float* gamma, co
                      const float* dy, const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ---- three-term bf16 split image (opt-in "bf16x3" feed-forward mode, kanvit/dense.py) --------------------------------
+ * v = hi + lo, hi = bf16(v), lo = bf16(v - hi).  Writes out[M][3K] (bf16) = [hi|hi|lo] (pattern 0) or [hi|lo|hi]
+ * (pattern 1) of  v = x (+ bias[K]) (ReLU if relu) (zeroed where mask_hi[m][k] <= 0, a bf16 image with row stride
+ * mask_ld elements): an fp32-accurate (~5e-6) product through ONE bf16 GEMM over a 3K-long axis, pattern-0 image times
+ * pattern-1 image.  Replaces nothing in the reference (model.py:25-29 runs fp32 nn.Linear); K % 8 == 0.           */
+int kanvit_split3_bf16(int64_t M, int K, const float* x, const float* bias, int relu, const void* mask_hi, int64_t mask_ld,
+                       void* out, int pattern, void* stream);
+
 /* ---- per-family named entry points (SURVEY.md section 8b naming) ----------------------------
  * kanvit_<family>_{fwd,bwd_input,bwd_weight} are kanvit_layer_* with d->family checked;
  * kanvit_<family>_qkv_* additionally require groups == 3 * x_group_mod (one launch for all

@@ -65,6 +65,7 @@ SYMBOLS = {
     "kanvit_addln_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "kanvit_addln_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
     "kanvit_addln_bwd": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kanvit_split3_bf16": (C.c_int, [C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int64, _P, C.c_int, _P]),
 }
 for _f in FAMILY_NAMES:
     SYMBOLS[f"kanvit_{_f}_fwd"] = (C.c_int, _LAYER_FWD)

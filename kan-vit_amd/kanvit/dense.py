@@ -88,3 +88,84 @@ def dense(x: torch.Tensor, linear: torch.nn.Linear, relu: bool = False) -> torch
     """linear(x) (then ReLU if asked) for a 2-D x, with the token-split weight gradient in backward."""
     assert x.dim() == 2
     return _DenseFn.apply(x, linear.weight, linear.bias, relu)
+
+
+# ------------------------------------------------------------------------------------------------
+# opt-in "bf16x3" feed-forward: fp32-accurate GEMMs on the bf16 matrix cores
+# ------------------------------------------------------------------------------------------------
+# The fp32 matrix pipe of MI355X peaks at 157 TFLOP/s and the stock fp32 GEMMs already run at 125-143 of it; they are 65 %
+# of the fp32 train step.  Splitting every fp32 operand into two bf16 terms (v = hi + lo) and forming a.b as
+# hi.hi + hi.lo + lo.hi -- ONE bf16 GEMM over a three times longer K axis, fp32 accumulate -- reproduces the fp32 product
+# to ~5e-6 relative (the fp32 GEMM itself is at 1.4e-6, tools/probe_split_gemm.py) at 2.5x the speed.  Whether the step
+# may spend part of its 1e-4 parity budget here is a policy decision, so this is OFF by default:
+#     kanvit.dense.FF_MODE = "bf16x3"      (bench.py --ff bf16x3, or KANVIT_FF=bf16x3)
+FF_MODE = "fp32"
+
+
+def _split3(x: torch.Tensor, pattern: int, bias=None, relu=False, mask=None) -> torch.Tensor:
+    from . import _lib
+    import ctypes as C
+    L = _lib.lib()
+    M, K = x.shape
+    out = torch.empty(M, 3 * K, device=x.device, dtype=torch.bfloat16)
+    x = x.contiguous()
+    _lib.check(L.kanvit_split3_bf16(M, K, C.c_void_p(x.data_ptr()), None if bias is None else C.c_void_p(bias.data_ptr()),
+                                    int(relu), None if mask is None else C.c_void_p(mask.data_ptr()),
+                                    0 if mask is None else mask.stride(0), C.c_void_p(out.data_ptr()), pattern,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kanvit_split3_bf16")
+    return out
+
+
+def _wgrad3(G3: torch.Tensor, X3: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """dW[N, K] = G^T X from the pattern-0 images G3 = [g_hi|g_hi|g_lo] ([M, 3N]) and X3 = [x_hi|x_hi|x_lo] ([M, 3K]):
+    g_hi^T [x_hi | x_lo] + g_lo^T x_hi, token axis split into slabs like the fp32 path."""
+    M = G3.shape[0]
+    S = wgrad_slabs(M, N, K)
+    g, x = G3.view(S, M // S, 3 * N), X3.view(S, M // S, 3 * K)
+    t1 = torch.bmm(g[:, :, :N].transpose(1, 2), x[:, :, K:], out_dtype=torch.float32).sum(0)        # [N, 2K]
+    t2 = torch.bmm(g[:, :, 2 * N:].transpose(1, 2), x[:, :, :K], out_dtype=torch.float32).sum(0)    # [N, K]
+    return t1[:, :K] + t1[:, K:] + t2
+
+
+class _FFSplitFn(torch.autograd.Function):
+    """Linear -> ReLU -> Linear (reference model.py:25-29) with every GEMM as a three-term bf16 split product."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w1, b1, w2, b2):
+        A3 = _split3(x, 0)
+        y1 = torch.mm(A3, _split3(w1, 1).t(), out_dtype=torch.float32)
+        H3 = _split3(y1, 0, bias=b1, relu=True)
+        y2 = torch.mm(H3, _split3(w2, 1).t(), out_dtype=torch.float32)
+        y2.add_(b2)
+        ctx.save_for_backward(A3, H3, w1, w2)
+        return y2
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy2):
+        A3, H3, w1, w2 = ctx.saved_tensors
+        N1, K = w1.shape
+        N2 = w2.shape[0]
+        dy2 = dy2.contiguous().float()
+        D3 = _split3(dy2, 0)
+        dH = torch.mm(D3, _split3(w2.t().contiguous(), 1).t(), out_dtype=torch.float32)          # [M, N1]
+        DP3 = _split3(dH, 0, mask=H3)                                                                # ReLU mask from H's hi part
+        dx = torch.mm(DP3, _split3(w1.t().contiguous(), 1).t(), out_dtype=torch.float32)           # [M, K]
+        dw2 = _wgrad3(D3, H3, N2, N1)
+        dw1 = _wgrad3(DP3, A3, N1, K)
+        db2 = dy2.sum(0)
+        db1 = DP3[:, :N1].sum(0, dtype=torch.float32) + DP3[:, 2 * N1:].sum(0, dtype=torch.float32)
+        return dx, dw1, db1, dw2, db2
+
+
+def feed_forward(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear) -> torch.Tensor:
+    """lin2(relu(lin1(x))) for a 2-D x: the stock-GEMM path (`dense`) or, when FF_MODE == "bf16x3" and the shapes allow
+    it (CUDA, fp32 parameters, widths multiples of 8, biases present, M divisible into slabs), the split-bf16 path."""
+    import os
+    mode = os.environ.get("KANVIT_FF", FF_MODE)
+    if (mode == "bf16x3" and x.is_cuda and lin1.bias is not None and lin2.bias is not None and
+            lin1.in_features % 8 == 0 and lin1.out_features % 8 == 0 and lin2.out_features % 8 == 0 and
+            not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32)):
+        return _FFSplitFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    return dense(dense(x, lin1, relu=True), lin2)

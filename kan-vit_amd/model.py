@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from attention import MSA, FlashAttention
-from kanvit.dense import dense
+from kanvit.dense import feed_forward
 from kanvit.ops import add_layernorm
 from models.cheby import ChebyKANLayer
 from models.effkan import KANLinear
@@ -46,8 +46,7 @@ class TransformerBlock(nn.Module):
         # The two Linears go through kanvit.dense: stock GEMMs, but with the weight gradient split over tokens
         # (the unsplit library kernel fills 36 of 256 CUs: 2.2 ms -> 0.83 ms per call).
         b, n, d = x.shape
-        h = dense(h2.reshape(b * n, d), self.ff[0], relu=True)       # bias + ReLU in the GEMM epilogue
-        return x, dense(h, self.ff[2]).view(b, n, d)
+        return x, feed_forward(h2.reshape(b * n, d), self.ff[0], self.ff[2]).view(b, n, d)   # bias + ReLU in the GEMM epilogue
 
 
 def _patch_embedding(kind, in_dim, d):
