@@ -2083,8 +2083,8 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_weight_kernel(const LayerArgs a)
 // Work-group = 4 consecutive wave units (feature block fastest), so neighbouring waves share dY (and x across tile sets).
 // fp32: v_mfma_f32_32x32x2f32, 2 tokens per step (lane half = token parity).  bf16 flag: v_mfma_f32_32x32x16_bf16, 16
 // tokens per step, lane half h owns tokens 8h..8h+7 of the step.  Rows beyond the slab end are clamped for x and zeroed
-// for dY.  Partials go to slab[blockIdx.y][g][k][o]; kan_slab_reduce_kernel sums them in order.
-// grid (ceil(units / 4), slabs), 256 threads = 4 wave units.
+// for dY.  Partials go to slab[s][g][k][o]; kan_slab_reduce_kernel sums them in order.
+// grid ceil(units * slabs / 4), 256 threads = 4 (slab, wave unit) pairs, unit fastest.
 // =============================================================================================
 template <int FAM, int GP, int NOT, bool BF>
 __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
@@ -2098,10 +2098,12 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     // wave unit u = (basis group, column-tile set, feature block), feature block fastest: the 4 waves of a work-group are
     // always 4 live units (a partly populated work-group would leave SIMDs idle: one wave fills a SIMD's register file,
     // so the next work-group cannot start until ALL four SIMDs are free)
-    const int u = (int)blockIdx.x * 4 + wave;
-    if (u >= nfb * nos * nbg) return;
+    const int units = nfb * nos * nbg;
+    const long long gw = (long long)blockIdx.x * 4 + wave;       // global wave index over (slab, unit), unit fastest
+    if (gw >= (long long)units * a.msplit) return;
+    const int u = (int)(gw % units), slab = (int)(gw / units);
     const int fb = u % nfb, os = (u / nfb) % nos, bg = u / (nfb * nos);
-    const long long ms = (long long)blockIdx.y * a.rows_per_split;
+    const long long ms = (long long)slab * a.rows_per_split;
     long long me = ms + a.rows_per_split;
     if (me > a.M) me = a.M;
     const int len = (int)(me - ms);
@@ -2224,7 +2226,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     }
 
     // dW partial of this slab: row k = (fb*32 + acc row)*GP + j, 32 contiguous columns per row
-    float* base = a.slab + (long long)blockIdx.y * ((long long)a.groups * a.K * a.O);
+    float* base = a.slab + (long long)slab * ((long long)a.groups * a.K * a.O);
 #pragma unroll
     for (int i = 0; i < NOT; ++i) {
         if (tg[i] < 0) continue;
@@ -2936,7 +2938,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
 template <int FAM, int GP, int NOT>
 int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
     const long long units = (long long)p.nbg * p.nfb * p.nos;
-    dim3 grid((unsigned)((units + 3) / 4), (unsigned)p.slabs, 1);
+    dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
     if (bf)
         hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     else
