@@ -143,3 +143,24 @@ def test_init_statistics_follow_reference():
     k = KANLinear(32, 32)
     assert k.spline_weight.shape == (32, 32, 8) and float(k.spline_weight.abs().max()) < 0.2
     assert torch.isfinite(k.spline_weight).all()
+
+
+def test_assembly_helpers_validate_arguments_without_a_gpu(lib):
+    """kanvit_addln_* / kanvit_split3_bf16 reject bad shapes before touching the device (error code + message), return 0 for
+    empty inputs, and report workspace sizes."""
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    # last dim must be a multiple of 4 in [4, 1024]
+    for D in (3, 10, 1028):
+        assert lib.kanvit_addln_fwd(4, D, 1e-5, p, None, p, p, None, p, p, p, None) != 0
+        assert b"kanvit_addln_fwd" in lib.kanvit_last_error()
+    assert lib.kanvit_addln_fwd(0, 64, 1e-5, p, None, p, p, None, p, p, p, None) == 0          # no rows: nothing to do
+    assert lib.kanvit_addln_bwd_workspace(0, 64) == 0
+    ws = lib.kanvit_addln_bwd_workspace(25216, 768)
+    assert ws > 0 and ws % (2 * 768 * 4) == 0                                                    # whole [2][D] partials
+    assert lib.kanvit_addln_bwd(4, 10, p, p, p, p, p, None, p, p, p, p, 1 << 20, None) != 0
+    # split image: K must be a positive multiple of 8
+    for K in (0, 4, 12):
+        assert lib.kanvit_split3_bf16(4, K, p, None, 0, None, 0, p, 0, None) != 0
+        assert b"kanvit_split3_bf16" in lib.kanvit_last_error()
+    assert lib.kanvit_split3_bf16(0, 16, p, None, 0, None, 0, p, 0, None) == 0
