@@ -79,6 +79,7 @@ struct AttnArgs {
     float* dk;
     float* dv;
     float* delta;
+    float* ds;        // [B*H][NP][NP] dS = P*scale*(dP - delta), written by attn_bwd_kv2_kernel<.., DSOUT>, read by attn_bwd_dq_kernel
     long long qsb, qsh, qsn, ksb, ksh, ksn, vsb, vsh, vsn, osb, osh, osn;
     int B, H, N, D, causal, nkt, vec;
     float scale;
@@ -895,7 +896,7 @@ __device__ __forceinline__ void store_acc_rows(float* __restrict__ rowp, const f
         }
 }
 
-template <int DT, bool BF>
+template <int DT, bool BF, bool DSOUT>
 __global__ __launch_bounds__(512) void attn_bwd_kv2_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int D = 32 * DT, KS = D + 1, KB = D + 8, NTHR = 512, NW = 8;
@@ -982,6 +983,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kv2_kernel(const AttnArgs a) {
                 if (!key_ok || (a.causal && key > qrow)) p = 0.0f;
                 sacc[r] = p;
                 pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
+            }
+            if constexpr (DSOUT) {       // dS[q][key] for the dQ kernel: row = q (register), 32 consecutive keys per lane half
+                float* dsp = a.ds + ((long long)bh * NP + qt * 32) * NP + jt * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsp[(long long)kv_acc_row(r, hf) * NP] = pacc[r];
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
             if constexpr (BF) {
@@ -1120,6 +1126,54 @@ __global__ __launch_bounds__(512) void attn_bwd_q2_kernel(const AttnArgs a) {
     }
 }
 
+// dQ from the stored dS (fp32 path): dQ^T[d][q] = sum_key K^T[d][key] dS[q][key] -- one product instead of the three of
+// attn_bwd_q2_kernel (S and dP are not recomputed, no exponentials).  K in LDS (A operand, lanes walk d); the B operand is 16
+// consecutive keys of the lane's own dS row per key tile (lane half h takes keys 16h + s), float4 loads one tile ahead.
+template <int DT>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, KS = D + 1, NTHR = 512, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32;
+    float* K_s = smem;                    // [NP][KS]
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
+    load_tile<DT>(K_s, kb, a.ksn, 0, NP, N, D, tid, NTHR, true);
+    __syncthreads();
+    for (int qt = wave; qt < nkt; qt += NW) {
+        const int qrow = qt * 32 + l31;
+        const float* dsrow = a.ds + ((long long)bh * NP + qrow) * NP + 16 * hf;
+        f32x16 dqacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+        f32x4 nxt[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nxt[e] = *reinterpret_cast<const f32x4*>(dsrow + 4 * e);
+        for (int j = 0; j < nkt; ++j) {
+            float dsv[16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dsv[4 * e + c] = nxt[e][c];
+            if (j + 1 < nkt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nxt[e] = *reinterpret_cast<const f32x4*>(dsrow + (j + 1) * 32 + 4 * e);
+            }
+            const float* kr = K_s + (j * 32 + 16 * hf) * KS + l31;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[s2 * KS + dt * 32], dsv[s2], dqacc[dt], 0, 0, 0);
+            }
+        }
+        if (qrow < N) store_acc_rows<DT>(dqb + (long long)qrow * a.qsn, dqacc, hf, 1.0f);
+    }
+}
+
 int check_desc(const kanvit_attn_desc* d, const char* who) {
     if (!d) return kv_fail(KANVIT_EINVAL, "%s: null descriptor", who);
     if (d->B < 0 || d->H < 1 || d->N < 1 || d->D < 1) return kv_fail(KANVIT_EINVAL, "%s: bad sizes", who);
@@ -1203,11 +1257,26 @@ int launch_bwd2(const AttnArgs& a, hipStream_t st) {
     const size_t lds_q = BF ? 2 * row + tr : 2 * f32img;
     static bool attr_done = false;
     if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv2_kernel<DT, BF>), 160 * 1024));
+        KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv2_kernel<DT, BF, false>), 160 * 1024));
         KV_HIP_CHECK(kv_allow_lds((attn_bwd_q2_kernel<DT, BF>), 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kv2_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_kv, st, a);
+    if constexpr (!BF) {
+        if (a.ds) {      // dS spill: the key-stationary kernel stores dS, dQ is one plain product (5 MFMA products instead of 7)
+            static bool ds_attr_done = false;
+            if (!ds_attr_done) {
+                KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv2_kernel<DT, false, true>), 160 * 1024));
+                KV_HIP_CHECK(kv_allow_lds((attn_bwd_dq_kernel<DT>), 160 * 1024));
+                ds_attr_done = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_kv2_kernel<DT, false, true>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_kv, st, a);
+            KV_LAUNCH_CHECK("attn_bwd_kv2_kernel");
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<DT>), dim3((unsigned)(a.B * a.H)), dim3(512), f32img, st, a);
+            KV_LAUNCH_CHECK("attn_bwd_dq_kernel");
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((attn_bwd_kv2_kernel<DT, BF, false>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_kv, st, a);
     KV_LAUNCH_CHECK("attn_bwd_kv2_kernel");
     hipLaunchKernelGGL((attn_bwd_q2_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_q, st, a);
     KV_LAUNCH_CHECK("attn_bwd_q2_kernel");
@@ -1258,9 +1327,20 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     return d->D <= 32 ? dispatch_fwd<1, false>(a, st) : dispatch_fwd<2, false>(a, st);
 }
 
+// rowsum(dO*O) [B*H*N] (rounded up to 16 bytes), then -- exact fp32 path with D in {32, 64} and N >= 64 only -- dS [B*H][NP][NP]
+static size_t attn_delta_bytes(const kanvit_attn_desc* d) { return (sizeof(float) * (size_t)d->B * d->H * d->N + 15) / 16 * 16; }
+static bool attn_ds_spill(const kanvit_attn_desc* d) {
+    return !(d->flags & KANVIT_FLAG_BF16_MFMA) && (d->D == 32 || d->D == 64) && d->N >= 64 && !d->causal && !getenv("KANVIT_ATTN_NO_DS") &&
+           !getenv("KANVIT_ATTN_V1");
+}
 size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d) {
     if (!d || d->B < 0 || d->H < 1 || d->N < 1) return 0;
-    return sizeof(float) * (size_t)d->B * d->H * d->N;
+    size_t n = attn_delta_bytes(d);
+    if (attn_ds_spill(d)) {
+        const size_t np = (size_t)(d->N + 31) / 32 * 32;
+        n += sizeof(float) * (size_t)d->B * d->H * np * np;
+    }
+    return n;
 }
 
 /* dq/dk/dv are fully written (no accumulation into the outputs). */
@@ -1278,6 +1358,7 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     AttnArgs a = make_args(d);
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse_in = lse; a.d_o = d_o;
     a.dq = dq; a.dk = dk; a.dv = dv; a.delta = delta_ws; a.delta_in = delta_ws;
+    a.ds = attn_ds_spill(d) ? (float*)((char*)workspace + attn_delta_bytes(d)) : nullptr;
     a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)d->B * d->H * d->N;

@@ -256,7 +256,9 @@ def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale, flags=0):
     nbytes = int(L.kanvit_attn_bwd_workspace(C.byref(d)))
     ws = torch.empty(max(nbytes // 4, 1), device=q.device, dtype=torch.float32)
     B, H, N, D = q.shape
-    with torch.cuda.device(q.device), _timed("attn_bwd" + ("_bf16" if flags & 1 else ""), 14 * B * H * N * N * D, 4 * 9 * B * H * N * D):
+    # algorithmic work of a recompute backward: 5 products (S, dP, dV, dK, dQ) = 2.5x the forward; the two-kernel bf16 path
+    # executes 7 (S and dP twice), the fp32 dS-spill path exactly 5
+    with torch.cuda.device(q.device), _timed("attn_bwd" + ("_bf16" if flags & 1 else ""), 10 * B * H * N * N * D, 4 * 9 * B * H * N * D):
         check(L.kanvit_attn_bwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(do), _ptr(dq), _ptr(dk),
                                 _ptr(dv), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_attn_bwd")
 

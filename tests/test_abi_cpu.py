@@ -77,7 +77,12 @@ def test_descriptor_layout_and_errors(lib):
     a.N, a.D = 197, 63
     assert lib.kanvit_attn_fwd(ctypes.byref(a), None, None, None, None, None, None) == -22
     a.D = 64
-    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == 2 * 3 * 197 * 4
+    # rowsum(dO*O) per row (16-byte rounded) + the dS spill of the exact fp32 path: [B*H][NP][NP], NP = 224
+    delta = (2 * 3 * 197 * 4 + 15) // 16 * 16
+    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta + 2 * 3 * 224 * 224 * 4
+    a.flags = 1                                   # bf16 matrix-core mode keeps the recompute kernels: no spill
+    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta
+    a.flags = 0
 
 
 def test_no_cpu_fallback():
