@@ -184,8 +184,17 @@ __global__ __launch_bounds__(256) void addln_reduce_kernel(const float* __restri
     const int cl = threadIdx.x & 31, k = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.0f;
-    if (c < 2 * D)
-        for (int w = k; w < nparts; w += 8) s += part[(long long)w * 2 * D + c];
+    if (c < 2 * D) {
+        int w = k;
+        for (; w + 56 < nparts; w += 64) {            // 8 independent loads in flight per thread, added in order
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = part[(long long)(w + 8 * j) * 2 * D + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += t[j];
+        }
+        for (; w < nparts; w += 8) s += part[(long long)w * 2 * D + c];
+    }
     sub[k][cl] = s;
     __syncthreads();
     if (k == 0 && c < 2 * D) {
