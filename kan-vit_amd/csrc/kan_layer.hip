@@ -2727,6 +2727,7 @@ int try_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
     if constexpr (FAM == KV_SINE) {   // attention.py:140 builds the per-head sine mappings with grid_size = 4; 5 is the layer's default
         if (a.GP == 4) return launch_bwd_input_reg<FAM, 4, 4>(a, st);
         if (a.GP == 5) return launch_bwd_input_reg<FAM, 5, 5>(a, st);
+        if (a.GP == 28) return launch_bwd_input_reg<FAM, 28, 7>(a, st);      // the G = 28 patch embedding (model.py:72)
     }
     return 1;
 }
