@@ -343,15 +343,23 @@ struct BasisGenP {
     int j0;
     bool in;
 
-    __device__ __forceinline__ void prepare(const BasisArgs& b, int feat) {
+    // `GP` here is the number of basis functions this generator produces: all of them, or a window [j0, j0 + GP) of a
+    // wide basis (SINE / FOURIER with G = 28, contracted in several passes); next(j) takes the index INSIDE the window.
+    int j0w;
+    float s1, c1r, sk, ck;
+    bool sin_half;
+    __device__ __forceinline__ void prepare(const BasisArgs& b, int feat, int j0 = 0) {
         G = b.G;
         inv_h = b.inv_h;
+        j0w = j0;
         if constexpr (FAM == KV_SINE) {
 #pragma unroll
             for (int j = 0; j < GP; ++j) {
-                c0[j] = b.bp[j];
-                c1[j] = b.bp[b.G + (long long)feat * b.G + j];
+                c0[j] = b.bp[j0 + j];
+                c1[j] = b.bp[b.G + (long long)feat * b.G + j0 + j];
             }
+        } else if constexpr (FAM == KV_FOURIER) {       // window lies inside the cos block (j0 < G) or the sin block
+            sin_half = j0 >= b.G;
         } else if constexpr (FAM == KV_RBF) {
 #pragma unroll
             for (int j = 0; j < GP; ++j) c0[j] = (j < b.G) ? b.bp[j] : 0.0f;
@@ -368,6 +376,10 @@ struct BasisGenP {
             t = kv_tanh(xv);
             p0 = 1.0f;
             p1 = t;
+        } else if constexpr (FAM == KV_FOURIER) {       // cos / sin of k0*x directly (as the reference forms k*x), then rotate by x
+            kv_sincos(xv, s1, c1r);
+            const float k0 = (float)((sin_half ? j0w - G : j0w) + 1);
+            kv_sincos(__fmul_rn(k0, xv), sk, ck);
         } else if constexpr (FAM == KV_BSPLINE) {       // same arithmetic as kv_bspline_uniform
             const float tt = (xv - g0) * ih;
             const float fl = floorf(tt);
@@ -400,6 +412,12 @@ struct BasisGenP {
             if (j >= G) return kv_silu(x);
             const float d = (u - c0[j < NC0 ? j : 0]) * inv_h;
             return __expf(-d * d);
+        } else if constexpr (FAM == KV_FOURIER) {
+            const float v = sin_half ? sk : ck;
+            const float cn = ck * c1r - sk * s1;
+            sk = sk * c1r + ck * s1;
+            ck = cn;
+            return v;
         } else {   // SINE
             return kv_sin(__fadd_rn(__fmul_rn(x, c0[j < NC0 ? j : 0]), c1[j < NC1 ? j : 0]));
         }

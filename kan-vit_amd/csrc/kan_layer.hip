@@ -2086,9 +2086,11 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_weight_kernel(const LayerArgs a)
 // for dY.  Partials go to slab[s][g][k][o]; kan_slab_reduce_kernel sums them in order.
 // grid ceil(units * slabs / 4), 256 threads = 4 (slab, wave unit) pairs, unit fastest.
 // =============================================================================================
-template <int FAM, int GP, int NOT, bool BF>
+template <int FAM, int GP, int NOT, bool BF, int JC = GP>
 __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
                                                                  int shared, int nbg) {
+    constexpr int NJC = GP / JC;                  // wide bases (G = 28) are contracted in NJC windows of JC basis functions,
+                                                  // each its own wave unit (every window regenerates only its own values)
     constexpr bool RBF = (FAM == KV_RBF);
     constexpr int TS = BF ? 8 : 1;            // tokens per lane per step
     constexpr int UB = BF ? 1 : 4;            // steps per prefetch block
@@ -2098,11 +2100,12 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     // wave unit u = (basis group, column-tile set, feature block), feature block fastest: the 4 waves of a work-group are
     // always 4 live units (a partly populated work-group would leave SIMDs idle: one wave fills a SIMD's register file,
     // so the next work-group cannot start until ALL four SIMDs are free)
-    const int units = nfb * nos * nbg;
+    const int units = nfb * nos * nbg * NJC;
     const long long gw = (long long)blockIdx.x * 4 + wave;       // global wave index over (slab, unit), unit fastest
     if (gw >= (long long)units * a.msplit) return;
     const int u = (int)(gw % units), slab = (int)(gw / units);
-    const int fb = u % nfb, os = (u / nfb) % nos, bg = u / (nfb * nos);
+    const int fb = u % nfb, os = (u / nfb) % nos, jc = (u / (nfb * nos)) % NJC, bg = u / (nfb * nos * NJC);
+    const int j0 = jc * JC;
     const long long ms = (long long)slab * a.rows_per_split;
     long long me = ms + a.rows_per_split;
     if (me > a.M) me = a.M;
@@ -2129,17 +2132,17 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     }
     const int g0 = bg;                 // basis parameters: identical for every group of a shared launch
     const BasisArgs b = make_basis(a, g0);
-    BasisGenP<FAM, GP> proto;          // knots / centres / frequencies / phases of this lane's feature, loaded once
-    proto.prepare(b, f);
+    BasisGenP<FAM, JC> proto;          // knots / centres / frequencies / phases of this lane's feature, loaded once
+    proto.prepare(b, f, j0);
 
     const float* xcol = a.x + (long long)gx * a.I + f;
     const float* ucol = RBF ? (a.u ? a.u + (long long)g0 * a.I + f : xcol) : xcol;
     const long long ldu = RBF ? (a.u ? a.ldu : a.ldx) : a.ldx;
     const float* dycol = a.dy + l31;
 
-    f32x16 acc[GP][NOT];
+    f32x16 acc[JC][NOT];
 #pragma unroll
-    for (int j = 0; j < GP; ++j)
+    for (int j = 0; j < JC; ++j)
 #pragma unroll
         for (int i = 0; i < NOT; ++i)
 #pragma unroll
@@ -2185,10 +2188,10 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                 if constexpr (!BF) {
 #pragma unroll
                     for (int t = 0; t < NTOK; ++t) {
-                        BasisGenP<FAM, GP> gen = proto;
+                        BasisGenP<FAM, JC> gen = proto;
                         gen.init(cx[t], RBF ? cu[t] : 0.0f);
 #pragma unroll
-                        for (int j = 0; j < GP; ++j) {
+                        for (int j = 0; j < JC; ++j) {
                             const float av = gen.next(j);
 #pragma unroll
                             for (int i = 0; i < NOT; ++i)
@@ -2196,14 +2199,14 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                         }
                     }
                 } else {
-                    unsigned af[GP][4];
+                    unsigned af[JC][4];
 #pragma unroll
                     for (int ep = 0; ep < 4; ++ep) {
-                        BasisGenP<FAM, GP> g0_ = proto, g1_ = proto;
+                        BasisGenP<FAM, JC> g0_ = proto, g1_ = proto;
                         g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
                         g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
 #pragma unroll
-                        for (int j = 0; j < GP; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
+                        for (int j = 0; j < JC; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
                     }
                     bf16x8_t bfr[NOT];
 #pragma unroll
@@ -2213,7 +2216,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                         bfr[i] = __builtin_bit_cast(bf16x8_t, u4);
                     }
 #pragma unroll
-                    for (int j = 0; j < GP; ++j) {
+                    for (int j = 0; j < JC; ++j) {
                         const u32x4 a4 = {af[j][0], af[j][1], af[j][2], af[j][3]};
                         const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, a4);
 #pragma unroll
@@ -2234,11 +2237,11 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         const int col0 = (tt % otpg) * 32;
         float* gb = base + (long long)tg[i] * a.K * a.O + col0 + l31;
 #pragma unroll
-        for (int j = 0; j < GP; ++j)
+        for (int j = 0; j < JC; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int fr = fb * 32 + kv_acc_row(r, hf);
-                gb[((long long)fr * GP + j) * a.O] = acc[j][i][r];
+                gb[((long long)fr * GP + j0 + j) * a.O] = acc[j][i][r];
             }
     }
 }
@@ -2890,7 +2893,7 @@ int launch_bwd_weight(const LayerArgs& a, const BwPlan& p, bool bf, hipStream_t 
 // ---- register-form (streaming) weight gradient -----------------------------------------------------
 struct BwRegPlan {
     bool ok;
-    int gp, nt, nfb, nos, tiles_per_bg, nbg, shared, slabs;
+    int gp, nt, nfb, nos, tiles_per_bg, nbg, shared, slabs, njc;
     long long rows_per_slab;
     size_t ws_bytes;
 };
@@ -2898,6 +2901,7 @@ struct BwRegPlan {
 BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     BwRegPlan p{};
     if (getenv("KANVIT_NO_REG") || getenv("KANVIT_NO_REG_BW")) return p;
+    p.njc = 1;
     p.gp = gp_of(d);
     const int fam = d->family;
     if (fam == KANVIT_LINEAR && p.gp == 1) p.nt = 6;
@@ -2908,6 +2912,8 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
              getenv("KANVIT_REG_BW_BSPLINE")) p.nt = 2;
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 2;
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
+    else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }          // windows of 4 basis functions
+    else if (fam == KANVIT_FOURIER && p.gp == 56) { p.nt = 4; p.njc = 14; }
     else return p;
     if (d->I % 32 || d->O % 32 || d->M < 256) return p;
     const int nshare = d->groups / d->x_group_mod;
@@ -2918,7 +2924,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     p.nos = (p.tiles_per_bg + p.nt - 1) / p.nt;
     // one live wave per SIMD (the accumulator block fills the register file): size the slab count so that the live waves
     // (work-groups whose 2x2 wave grid is only partly populated retire their idle waves at once) cover the chip r times
-    const long long units = (long long)p.nbg * p.nfb * p.nos;
+    const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
     long long r = 1;
     while (4LL * N_CU * r < units) ++r;
     long long S = 4LL * N_CU * r / units;
@@ -2936,14 +2942,14 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     return p;
 }
 
-template <int FAM, int GP, int NOT>
+template <int FAM, int GP, int NOT, int JC = GP>
 int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
-    const long long units = (long long)p.nbg * p.nfb * p.nos;
+    const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
     dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
     if (bf)
-        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     else
-        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
     return 0;
 }
@@ -2955,7 +2961,9 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
         case KANVIT_BSPLINE: return launch_bwd_weight_reg<KV_BSPLINE, 9, 2>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:
+            if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE, 28, 4, 4>(a, p, bf, st);
             return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE, 5, 2>(a, p, bf, st);
+        case KANVIT_FOURIER: return launch_bwd_weight_reg<KV_FOURIER, 56, 4, 4>(a, p, bf, st);
         default: return kv_fail(KANVIT_EINVAL, "internal: register weight-gradient dispatch");
     }
 }
