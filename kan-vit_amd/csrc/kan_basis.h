@@ -362,7 +362,7 @@ struct BasisGenP {
             sin_half = j0 >= b.G;
         } else if constexpr (FAM == KV_RBF) {
 #pragma unroll
-            for (int j = 0; j < GP; ++j) c0[j] = (j < b.G) ? b.bp[j] : 0.0f;
+            for (int j = 0; j < GP; ++j) c0[j] = (j0 + j < b.G) ? b.bp[j0 + j] : 0.0f;
         } else if constexpr (FAM == KV_BSPLINE) {       // uniform knots (host-checked)
             g0 = b.bp[0];
             nkm1 = b.nk - 1;
@@ -404,12 +404,13 @@ struct BasisGenP {
             p1 = p2;
             return p2;
         } else if constexpr (FAM == KV_BSPLINE) {
-            if (j >= G) return kv_silu(x);
-            const int e = j - (j0 - 3);
+            const int jg = j0w + j;
+            if (jg >= G) return kv_silu(x);
+            const int e = jg - (j0 - 3);
             const float v = e == 0 ? bv[0] : (e == 1 ? bv[1] : (e == 2 ? bv[2] : bv[3]));
             return (in && e >= 0 && e < 4) ? v : 0.0f;
         } else if constexpr (FAM == KV_RBF) {
-            if (j >= G) return kv_silu(x);
+            if (j0w + j >= G) return kv_silu(x);
             const float d = (u - c0[j < NC0 ? j : 0]) * inv_h;
             return __expf(-d * d);
         } else if constexpr (FAM == KV_FOURIER) {

@@ -2910,7 +2910,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // it loses to the LDS-tile kernel (2.46 vs 1.15 ms on the ViT-B q|k|v launch) -- opt-in only until that is fixed
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 &&
              getenv("KANVIT_REG_BW_BSPLINE")) p.nt = 2;
-    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 2;
+    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
     else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }          // windows of 4 basis functions
     else if (fam == KANVIT_FOURIER && p.gp == 56) { p.nt = 4; p.njc = 14; }
