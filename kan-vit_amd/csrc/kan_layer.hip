@@ -2928,7 +2928,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     long long r = 1;
     while (4LL * N_CU * r < units) ++r;
     long long S = 4LL * N_CU * r / units;
-    const long long smax = d->M / 256;
+    const long long smax = d->M / 64;             // at least 64 tokens per slab (small M: parallelism beats slab traffic)
     if (S > smax) S = smax;
     if (S < 1) S = 1;
     if (S > 65535) S = 65535;
