@@ -2252,7 +2252,15 @@ __global__ __launch_bounds__(256) void kan_slab_reduce_kernel(const float* __res
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
         float s = slab[e];
-        for (int ms = 1; ms < msplit; ++ms) s += slab[(long long)ms * total + e];
+        int ms = 1;
+        for (; ms + 7 < msplit; ms += 8) {            // eight loads in flight, added in slab order
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = slab[(long long)(ms + j) * total + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += t[j];
+        }
+        for (; ms < msplit; ++ms) s += slab[(long long)ms * total + e];
         dw[e] = s;
     }
 }

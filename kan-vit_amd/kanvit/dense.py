@@ -18,13 +18,13 @@ _CUS = 256
 
 def wgrad_slabs(M: int, N: int, K: int) -> int:
     """Number of token slabs: the smallest divisor of M (<= 32) that yields >= one macro-tile per CU while keeping at
-    least 512 tokens per slab; 1 when the output alone already fills the chip or M is too small to split."""
+    least 128 tokens per slab; 1 when the output alone already fills the chip or M is too small to split."""
     tiles = -(-N // _TILE) * -(-K // _TILE)
     if tiles >= _CUS:
         return 1
     best = 1
     for s in range(2, 33):
-        if M % s or M // s < 512:
+        if M % s or M // s < 128:
             continue
         best = s
         if s * tiles >= _CUS:
