@@ -491,33 +491,28 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_kernel(const LayerArgs a) {
             for (int g = 0; g < GP; ++g) {
                 const float av = gen.next(g);
 #pragma unroll
-                for (int t = 0; t < NSH * NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wj[(2 * g) * WROW + t * 32], acc[t], 0, 0, 0);
+                for (int t = 0; t < NSH * NT; ++t)      // flipped product Y^T = W^T . Phi^T: accumulator rows = y columns
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wj[(2 * g) * WROW + t * 32], av, acc[t], 0, 0, 0);
             }
         }
         if (c + 1 < nch) store_w((c + 1) & 1);
         __syncthreads();
     }
 
-    // epilogue: per-wave transpose of each 32x32 tile through a private LDS patch, float4 row-segment stores
-    float* T_w = smem + wave * 32 * TS;           // W_s is dead after the last barrier (host sizes LDS >= 4*32*TS floats)
-    const int er = lane >> 3, ec = (lane & 7) * 4;    // 8 lanes cover one 32-float row segment; 8 rows per pass
+    // epilogue: with the flipped product, accumulator registers 4q..4q+3 of a tile are 4 consecutive y columns of the lane's
+    // OWN row (column 8q + 4hf + 0..3 of the tile): float4 stores straight from registers, no staging tile, no barrier
+    if (row < mrem) {
 #pragma unroll
-    for (int t = 0; t < NSH * NT; ++t) {
-        const int p = t / NT, nt = t - p * NT;
-        const int g = (NSH == 1) ? gs : p * nsets + gs;
+        for (int t = 0; t < NSH * NT; ++t) {
+            const int p = t / NT, nt = t - p * NT;
+            const int g = (NSH == 1) ? gs : p * nsets + gs;
+            float* yp = a.y + (m0 + row) * a.ldy + (long long)g * a.O + n0 + nt * 32 + 4 * hf;
+            const float* bp = a.bias ? a.bias + (long long)g * a.O + n0 + nt * 32 + 4 * hf : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) T_w[kv_acc_row(r, hf) * TS + l31] = acc[t][r];
-        f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)g * a.O + n0 + nt * 32 + ec);
-        float* yt = a.y + (m0 + wave * 32) * a.ldy + (long long)g * a.O + n0 + nt * 32 + ec;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rr = er + q * 8;
-            if (wave * 32 + rr < mrem) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(T_w + rr * TS + ec);
-                v += bv;
-                *reinterpret_cast<f32x4*>(yt + (long long)rr * a.ldy) = v;
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                if (bp) v += *reinterpret_cast<const f32x4*>(bp + 8 * q);
+                *reinterpret_cast<f32x4*>(yp + 8 * q) = v;
             }
         }
     }
