@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary measurements (bf16 autocast, bf16x3 feed-forward) of the default run")
+    ap.add_argument("--no-tuned-gemms", action="store_true",
+                    help="library-default kernel selection for the stock GEMMs instead of the recorded TunableOp results (kanvit/tuned.py)")
     ap.add_argument("--ff", choices=["fp32", "bf16x3"], default="fp32",
                     help="feed-forward GEMMs: stock fp32 (default, the parity path) or three-term bf16 split products (~5e-6 relative)")
     ap.add_argument("--bucket-mib", type=float, default=64.0)
@@ -178,6 +180,8 @@ def main():
     from kanvit import ops
     from model import VisionTransformer
     kdense.FF_MODE = args.ff
+    from kanvit import tuned as ktuned
+    tuned_ok = (not args.no_tuned_gemms) and not os.environ.get("PYTORCH_TUNABLEOP_ENABLED") and ktuned.enable_tuned_gemms()
 
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -277,7 +281,7 @@ def main():
             "config": {"workload": args.workload, "model_type": wl["type"], "image": list(wl["chw"]),
                        "n_patches": wl["n_patches"], "n_blocks": wl["n_blocks"], "d_hidden": wl["d"],
                        "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],
-                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3, fused)", "hip_graph": bool(use_graph), "loss_after": round(final_loss, 4)},
+                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3, fused)", "hip_graph": bool(use_graph), "tuned_gemm_selection": bool(tuned_ok), "loss_after": round(final_loss, 4)},
         }
         out.update(roofline_report(kern, args.steps, args.workload, wl["batch"]))
         if world == 1 and args.amp == "off" and not use_graph and not force_dp and not args.no_amp_leg:

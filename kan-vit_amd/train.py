@@ -61,6 +61,9 @@ def main(args):
                               n_heads=args.n_heads, out_d=args.out_d, type=args.model_type).to(device)
     kdp.broadcast_parameters(model)
     criterion = torch.nn.CrossEntropyLoss()
+    if device.type == "cuda":
+        from kanvit import tuned
+        tuned.enable_tuned_gemms()          # recorded kernel selections for the stock FF GEMMs (no run-time tuning)
     # fused=True on the GPU: same update rule, one multi-tensor kernel per parameter chunk instead of ~8 per step
     optimizer = Adam(model.parameters(), lr=args.learning_rate, fused=(device.type == "cuda"))
     reducer = kdp.GradReducer(model.parameters()) if world > 1 else None
