@@ -209,6 +209,34 @@ def test_bf16_weight_stationary_forward_matches_tile_kernel(fam, monkeypatch):
     assert 0 < err < 2e-2, (fam, err)
 
 
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("fam", ["cheby", "fast", "sine"])
+def test_weight_gradient_kernels_agree_and_are_deterministic(fam, amp, monkeypatch):
+    """The streaming register-form weight-gradient kernel and the LDS-tile kernel compute the same sums (same operand rounding,
+    fp32 accumulation in a different order), and each is bitwise reproducible run to run (slabs + ordered reduce, no atomics)."""
+    from attention import MSA
+    from kanvit import grouped
+    torch.manual_seed(4)
+    msa = MSA(256, 4, type=fam).to(DEV)
+    x = torch.randn(4 * 197 + 5, 256, device=DEV, requires_grad=True)
+    w = torch.randn(4 * 197 + 5, 768, device=DEV)
+
+    def grads():
+        msa.zero_grad()
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+        (y * w).sum().backward()
+        return torch.cat([p.grad.flatten() for p in msa.parameters() if p.grad is not None]).clone()
+
+    reg = [grads() for _ in range(3)]
+    assert all(torch.equal(reg[0], r) for r in reg[1:])
+    monkeypatch.setenv("KANVIT_NO_REG_BW", "1")
+    tile = [grads() for _ in range(2)]
+    assert torch.equal(tile[0], tile[1])
+    assert float((reg[0] - tile[0]).abs().max()) / float(tile[0].abs().max()) < 1e-5
+
+
 def test_bspline_non_uniform_or_differing_grids_take_the_general_path():
     """The closed-form / shared-basis shortcuts are only taken when the knot buffers allow it."""
     from attention import MSA
