@@ -37,6 +37,8 @@ WORKLOADS = {
     "vitb16-224-efficientkan": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="efficientkan", batch=128),
     "vitb16-224-sine": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="sine", batch=128),
     "vitb16-224-fourier": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="fourier", batch=128),
+    # BASELINE.json configs[4]: "SineKAN + FourierKAN ViT-B mixed blocks" -- blocks alternate sine / fourier (model.split_types)
+    "vitb16-224-sine+fourier": dict(chw=(3, 224, 224), n_patches=14, n_blocks=12, d=768, heads=12, out_d=100, type="sine,fourier", batch=128),
     # BASELINE.json configs[1]: MNIST-shaped defaults of model.py:49
     "mnist-cheby-tiny": dict(chw=(1, 28, 28), n_patches=7, n_blocks=4, d=64, heads=2, out_d=10, type="cheby", batch=128),
     # train.py:18-20 geometry
@@ -99,8 +101,45 @@ def cpu_baseline(model, wl, target_s=15.0):
                       f"per-sample x per-head loop, after a 1-image warm-up step ({t1:.2f} s)"}
 
 
+PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
+
+
+def _pmc_traffic(tag, workload, batch):
+    """HBM bytes per launch of launch class `tag` from the COMMITTED rocprofv3 --pmc passes of this workload (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs; (2*FETCH + WRITE) KiB per the guide's gfx950 rule).  It is a recorded
+    measurement of the same kernels, not a measurement of this run: `traffic_source` in the line says so."""
+    for fn in PMC_TRAFFIC_FILES:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            rec = pmc["kernels"].get(tag)
+            if pmc["workload"] == workload and pmc["per_gpu_batch"] == batch and rec and rec.get("write_kib") is not None:
+                return (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024, f"profiles/{fn} (separate --pmc passes of this workload, recorded)"
+        except Exception:
+            pass
+    return None, None
+
+
+def _roof(tag, k, workload, batch):
+    ai = k["alg_flops"] / k["alg_bytes"]
+    mfma_peak = PEAK_BF16_MFMA_TFLOPS if tag.endswith("_bf16") else PEAK_FP32_MFMA_TFLOPS
+    mfma_bound = ai > mfma_peak * 1e3 / PEAK_HBM_GBS                   # ridge: 19.7 flop/B fp32 pipe, 312 bf16 pipe
+    if mfma_bound:
+        roof = {"bound": "mfma", "achieved": k["TFLOP/s"], "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": round(k["TFLOP/s"] / mfma_peak, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": k["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(k["GB/s"] / PEAK_HBM_GBS, 4)}
+    roof["traffic"], src = _pmc_traffic(tag, workload, batch)
+    if src:
+        roof["traffic_source"] = src
+    roof.update({"kernel": tag, "avg_launch_ms": k["avg_ms"], "ms_per_step": k["ms_per_step"],
+                 "arith_intensity_flop_per_byte": round(ai, 1), "hbm_GB/s": k["GB/s"], "hbm_frac": round(k["GB/s"] / PEAK_HBM_GBS, 4)})
+    return roof
+
+
 def roofline_report(kern, steps, workload, batch):
-    """Per-op table + the roofline object of the dominant KAN op from the kernel timer's summary."""
+    """Per-op table + `roofline`: the hand-written op with the largest time per step over ALL launch classes (KAN layers and
+    attention alike) + `roofline_kan`: the same for the dominant fused KAN basis+contraction op (north_star's target kernel)."""
     res = {}
     kernels = {}
     for tag, r in kern.items():
@@ -111,27 +150,12 @@ def roofline_report(kern, steps, workload, batch):
                         "GB/s": round(gb, 1), "alg_flops": r["flops"], "alg_bytes": r["bytes"]}
     if not kernels:
         return res
-    dom = max((t for t in kernels if t.startswith(("qkv", "layer"))), key=lambda t: kernels[t]["ms_per_step"])
-    k = kernels[dom]
-    ai = k["alg_flops"] / k["alg_bytes"]
-    mfma_peak = PEAK_BF16_MFMA_TFLOPS if dom.endswith("_bf16") else PEAK_FP32_MFMA_TFLOPS
-    mfma_bound = ai > mfma_peak * 1e3 / PEAK_HBM_GBS                   # ridge: 19.7 flop/B fp32 pipe, 312 bf16 pipe
-    if mfma_bound:
-        roof = {"bound": "mfma", "achieved": k["TFLOP/s"], "peak": mfma_peak, "unit": "TFLOP/s",
-                "frac": round(k["TFLOP/s"] / mfma_peak, 4), "traffic": None}
-    else:
-        roof = {"bound": "hbm", "achieved": k["GB/s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(k["GB/s"] / PEAK_HBM_GBS, 4), "traffic": None}
-    try:      # HBM bytes per launch from the committed PMC pass, when it was taken on this very workload
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        rec = pmc["kernels"].get(dom)
-        if pmc["workload"] == workload and pmc["per_gpu_batch"] == batch and rec and rec["write_kib"] is not None:
-            roof["traffic"] = (2 * rec["fetch_kib"] + rec["write_kib"]) * 1024
-    except Exception:
-        pass
-    roof.update({"kernel": dom, "avg_launch_ms": k["avg_ms"], "arith_intensity_flop_per_byte": round(ai, 1),
-                 "hbm_GB/s": k["GB/s"], "hbm_frac": round(k["GB/s"] / PEAK_HBM_GBS, 4)})
-    res["roofline"] = roof
+    dom = max(kernels, key=lambda t: kernels[t]["ms_per_step"])
+    res["roofline"] = _roof(dom, kernels[dom], workload, batch)
+    kan = [t for t in kernels if t.startswith(("qkv", "layer"))]
+    if kan:
+        dk = max(kan, key=lambda t: kernels[t]["ms_per_step"])
+        res["roofline_kan"] = _roof(dk, kernels[dk], workload, batch)
     res["kernels"] = kernels
     res["custom_kernel_ms_per_step"] = round(sum(v["ms_per_step"] for v in kernels.values()), 3)
     return res
@@ -175,6 +199,7 @@ def main():
             dist.all_reduce(torch.zeros(1, device=dev))          # forces communicator creation (and its banner) now
             torch.cuda.synchronize()
 
+    from kanvit import _lib as klib
     from kanvit import dense as kdense
     from kanvit import dp as kdp
     from kanvit import ops
@@ -281,7 +306,9 @@ def main():
             "config": {"workload": args.workload, "model_type": wl["type"], "image": list(wl["chw"]),
                        "n_patches": wl["n_patches"], "n_blocks": wl["n_blocks"], "d_hidden": wl["d"],
                        "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],
-                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3, fused)", "hip_graph": bool(use_graph), "tuned_gemm_selection": bool(tuned_ok), "loss_after": round(final_loss, 4)},
+                       "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 0),
+                       "optimizer": "Adam(lr=1e-3, fused)", "hip_graph": bool(use_graph), "tuned_gemm_selection": bool(tuned_ok),
+                       "kanvit_switches": klib.active_config(), "loss_after": round(final_loss, 4)},
         }
         out.update(roofline_report(kern, args.steps, args.workload, wl["batch"]))
         if world == 1 and args.amp == "off" and not use_graph and not force_dp and not args.no_amp_leg:

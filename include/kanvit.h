@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KANVIT_ABI_VERSION 2
+#define KANVIT_ABI_VERSION 3
 
 /* error codes */
 #define KANVIT_OK 0
@@ -202,6 +202,12 @@ KANVIT_DECLARE_FAMILY(fourier)
 /* ---- misc ---------------------------------------------------------------------------------- */
 int kanvit_abi_version(void);
 const char* kanvit_last_error(void);
+/* Kernel-selection switches (KANVIT_NO_REG, KANVIT_NO_BF16, KANVIT_ATTN_V1, ...: fallback kernels for the parity tests and two
+ * tuning knobs).  The environment is read ONCE, on first use of the library -- never on the launch path; kanvit_config()
+ * returns the active set as "name=value ..." (all zero = the default kernels) so a measurement can say what it ran, and
+ * kanvit_config_reload() re-reads the environment (test hook; not for use while launches are in flight).            */
+const char* kanvit_config(void);
+int kanvit_config_reload(void);
 /* number of HIP devices visible, or a negative error code; does not initialise a context */
 int kanvit_device_count(void);
 

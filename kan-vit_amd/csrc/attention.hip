@@ -1206,11 +1206,7 @@ template <int DT, int NKT, bool BF>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
     constexpr int KS = 32 * DT + 1;
     const size_t lds = sizeof(float) * ((size_t)2 * a.nkt * 32 * KS + (size_t)4 * 32 * KS);
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(attn_fwd_kernel<DT, NKT, BF>, 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, attn_fwd_kernel<DT, NKT, BF>);
     hipLaunchKernelGGL((attn_fwd_kernel<DT, NKT, BF>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds, st, a);
     KV_LAUNCH_CHECK("attn_fwd_kernel");
     return 0;
@@ -1222,11 +1218,7 @@ int launch_fwd2(const AttnArgs& a, hipStream_t st) {
     const int NP = a.nkt * 32;
     const size_t lds = BF ? sizeof(unsigned short) * ((size_t)NP * (D + 8) + (size_t)D * (NP + 8))
                           : sizeof(float) * (size_t)2 * NP * (D + 1);
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(attn_fwd2_kernel<DT, NKT, BF>, 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, attn_fwd2_kernel<DT, NKT, BF>);
     hipLaunchKernelGGL((attn_fwd2_kernel<DT, NKT, BF>), dim3((unsigned)(a.B * a.H)), dim3(BF ? 256 : 512), lds, st, a);
     KV_LAUNCH_CHECK("attn_fwd2_kernel");
     return 0;
@@ -1234,7 +1226,7 @@ int launch_fwd2(const AttnArgs& a, hipStream_t st) {
 
 template <int DT, bool BF>
 int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
-    if (a.vec && a.D == 32 * DT && ((uintptr_t)a.out % 16 == 0) && !getenv("KANVIT_ATTN_V1")) {
+    if (a.vec && a.D == 32 * DT && ((uintptr_t)a.out % 16 == 0) && !kv_config().attn_v1) {
         if (a.nkt <= 1) return launch_fwd2<DT, 1, BF>(a, st);
         if (a.nkt <= 2) return launch_fwd2<DT, 2, BF>(a, st);
         if (a.nkt <= 4) return launch_fwd2<DT, 4, BF>(a, st);
@@ -1255,20 +1247,12 @@ int launch_bwd2(const AttnArgs& a, hipStream_t st) {
     const size_t f32img = sizeof(float) * (size_t)NP * (D + 1);
     const size_t lds_kv = (BF ? 2 * row + 2 * tr : 2 * f32img) + sizeof(float) * 2 * (size_t)NP;
     const size_t lds_q = BF ? 2 * row + tr : 2 * f32img;
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv2_kernel<DT, BF, false>), 160 * 1024));
-        KV_HIP_CHECK(kv_allow_lds((attn_bwd_q2_kernel<DT, BF>), 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv2_kernel<DT, BF, false>));
+    KV_ALLOW_LDS(160 * 1024, (attn_bwd_q2_kernel<DT, BF>));
     if constexpr (!BF) {
         if (a.ds) {      // dS spill: the key-stationary kernel stores dS, dQ is one plain product (5 MFMA products instead of 7)
-            static bool ds_attr_done = false;
-            if (!ds_attr_done) {
-                KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv2_kernel<DT, false, true>), 160 * 1024));
-                KV_HIP_CHECK(kv_allow_lds((attn_bwd_dq_kernel<DT>), 160 * 1024));
-                ds_attr_done = true;
-            }
+            KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv2_kernel<DT, false, true>));
+            KV_ALLOW_LDS(160 * 1024, (attn_bwd_dq_kernel<DT>));
             hipLaunchKernelGGL((attn_bwd_kv2_kernel<DT, false, true>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_kv, st, a);
             KV_LAUNCH_CHECK("attn_bwd_kv2_kernel");
             hipLaunchKernelGGL((attn_bwd_dq_kernel<DT>), dim3((unsigned)(a.B * a.H)), dim3(512), f32img, st, a);
@@ -1285,7 +1269,7 @@ int launch_bwd2(const AttnArgs& a, hipStream_t st) {
 
 template <int DT, bool BF>
 int launch_bwd(const AttnArgs& a, hipStream_t st) {
-    if (a.vec && a.D == 32 * DT && !getenv("KANVIT_ATTN_V1") &&
+    if (a.vec && a.D == 32 * DT && !kv_config().attn_v1 &&
         (((uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) % 16 == 0)) {
         const int NPc = a.nkt * 32;
         const size_t need = BF ? sizeof(unsigned short) * ((size_t)2 * NPc * (32 * DT + 8) + (size_t)2 * 32 * DT * (NPc + 8)) + 8 * (size_t)NPc
@@ -1296,12 +1280,8 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
     const int NP = a.nkt * 32;
     const size_t lds_kv = sizeof(float) * ((size_t)2 * NP * KS + 2 * (size_t)NP + (size_t)4 * 32 * KS);
     const size_t lds_q = sizeof(float) * ((size_t)2 * NP * KS + (size_t)4 * 32 * KS);
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds((attn_bwd_kv_kernel<DT, BF>), 160 * 1024));
-        KV_HIP_CHECK(kv_allow_lds((attn_bwd_q_kernel<DT, BF>), 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv_kernel<DT, BF>));
+    KV_ALLOW_LDS(160 * 1024, (attn_bwd_q_kernel<DT, BF>));
     hipLaunchKernelGGL((attn_bwd_kv_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_kv, st, a);
     KV_LAUNCH_CHECK("attn_bwd_kv_kernel");
     hipLaunchKernelGGL((attn_bwd_q_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(ATHR), lds_q, st, a);
@@ -1322,7 +1302,7 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
     a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !getenv("KANVIT_NO_BF16"))
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !kv_config().no_bf16)
         return d->D <= 32 ? dispatch_fwd<1, true>(a, st) : dispatch_fwd<2, true>(a, st);
     return d->D <= 32 ? dispatch_fwd<1, false>(a, st) : dispatch_fwd<2, false>(a, st);
 }
@@ -1330,8 +1310,8 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
 // rowsum(dO*O) [B*H*N] (rounded up to 16 bytes), then -- exact fp32 path with D in {32, 64} and N >= 64 only -- dS [B*H][NP][NP]
 static size_t attn_delta_bytes(const kanvit_attn_desc* d) { return (sizeof(float) * (size_t)d->B * d->H * d->N + 15) / 16 * 16; }
 static bool attn_ds_spill(const kanvit_attn_desc* d) {
-    return !(d->flags & KANVIT_FLAG_BF16_MFMA) && (d->D == 32 || d->D == 64) && d->N >= 64 && !d->causal && !getenv("KANVIT_ATTN_NO_DS") &&
-           !getenv("KANVIT_ATTN_V1");
+    return !(d->flags & KANVIT_FLAG_BF16_MFMA) && (d->D == 32 || d->D == 64) && d->N >= 64 && !d->causal && !kv_config().attn_no_ds &&
+           !kv_config().attn_v1;
 }
 size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d) {
     if (!d || d->B < 0 || d->H < 1 || d->N < 1) return 0;
@@ -1364,7 +1344,7 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     const long long rows = (long long)d->B * d->H * d->N;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
     KV_LAUNCH_CHECK("attn_delta_kernel");
-    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !getenv("KANVIT_NO_BF16"))
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !kv_config().no_bf16)
         return d->D <= 32 ? launch_bwd<1, true>(a, st) : launch_bwd<2, true>(a, st);
     return d->D <= 32 ? launch_bwd<1, false>(a, st) : launch_bwd<2, false>(a, st);
 }

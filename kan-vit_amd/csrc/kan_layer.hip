@@ -56,7 +56,6 @@ struct LayerArgs {
     int I, O, groups, xmod, G, GP, order, nk, has_base, K, IC, msplit, nchunks_n;
     float rbf_inv_h;
     int flags;
-    int dbg;   // KANVIT_DBG ablation mask (timing experiments only; results are wrong when non-zero)
 };
 
 __device__ __forceinline__ BasisArgs make_basis(const LayerArgs& a, int g) {
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_kernel(const LayerArgs a) {
     __syncthreads();
 
     for (int c = 0; c < nch; ++c) {
-        if (consumer && !(a.dbg & 8)) {
+        if (consumer) {
             // A[row = l31][k = hf] from A_s (lane = row), B[k = hf][col = l31] from W_s (lane = column)
             const float* ap = A_s + (c & 1) * ASZ + hf * AS + wave * 32 + l31;
             const float* wp = W_s + (c & 1) * WSZ + hf * WROW + l31;
@@ -300,9 +299,9 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_kernel(const LayerArgs a) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wp[(2 * s) * WROW + t * 32], acc[t], 0, 0, 0);
             }
         } else if (!consumer && c + 1 < nch) {
-            if (!(a.dbg & 1)) stage_w(c + 1, (c + 1) & 1);
-            if (!(a.dbg & 2)) gen_a(c + 1, (c + 1) & 1);
-            if (c + 2 < nch && !(a.dbg & 4)) stage_x(c + 2, c & 1);
+            stage_w(c + 1, (c + 1) & 1);
+            gen_a(c + 1, (c + 1) & 1);
+            if (c + 2 < nch) stage_x(c + 2, c & 1);
         }
         __syncthreads();
     }
@@ -932,7 +931,7 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_bf16_kernel(const LayerArgs a) {
     __syncthreads();
 
     for (int c = 0; c < nch; ++c) {
-        if (consumer && !(a.dbg & 8)) {
+        if (consumer) {
             const float* ap = A_s + (c & 1) * ASZ + (8 * hf) * AS + wave * 32 + l31;
             const unsigned short* wp = W_s + (size_t)(c & 1) * WSZ * 2 + ((size_t)hf * WROW + l31) * 8;
             for (int ks = 0; ks < KCP / 16; ++ks) {
@@ -949,16 +948,15 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_bf16_kernel(const LayerArgs a) {
                 }
             }
         } else if (!consumer && c + 1 < nch) {
-            if (!(a.dbg & 1)) load_w(c + 1);                 // loads in flight ...
-            if (c + 2 < nch && !(a.dbg & 4)) load_x(c + 2);
-            if (!(a.dbg & 2)) gen_a(c + 1, (c + 1) & 1);     // ... while the basis is evaluated ...
-            if (!(a.dbg & 1)) store_w((c + 1) & 1);          // ... and only then waited for
-            if (c + 2 < nch && !(a.dbg & 4)) store_x(c & 1);
+            load_w(c + 1);                 // loads in flight ...
+            if (c + 2 < nch) load_x(c + 2);
+            gen_a(c + 1, (c + 1) & 1);     // ... while the basis is evaluated ...
+            store_w((c + 1) & 1);          // ... and only then waited for
+            if (c + 2 < nch) store_x(c & 1);
         }
         __syncthreads();
     }
 
-    if (a.dbg & 32) return;
     // Epilogue: the accumulator layout gives each lane one dword per store (2 x 128 B per wave-instruction, 96
     // instructions per lane, consumer waves only) -- store-issue bound (0.12 of 0.33 ms in the bf16 kernel).
     // Instead park the tile in the idle operand buffers and let all 8 waves write float4 rows.
@@ -1601,7 +1599,6 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
     float* dxg = a.dx + (long long)gx * a.I;
     const int ldy = (int)a.ldy;
     const float* dyb = a.dy + m0 * a.ldy;           // uniform: this tile's dY rows
-    if (a.dbg & 32) return;                         // ablation: launch + residency cost only
 
     // ---- producer tasks ----
     auto stage_ops = [&](int t, int ci, int p, int cn) {
@@ -1791,7 +1788,7 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
         // step t completes a contraction: per (ci, p), or per ci when the groups share the basis
         const bool ends = (t < T) && (SHARED ? (rem == spc - 1) : (cn == ncn - 1));
         if (consumer) {
-            if (t < T && !(a.dbg & 8)) {
+            if (t < T) {
                 if constexpr (BF) {
                     const unsigned short* dYb = reinterpret_cast<const unsigned short*>(ops + (t & 1) * OPS);
                     const unsigned short* ap = dYb + (wave * 32 + l31) * OP + 8 * hf;
@@ -1817,8 +1814,8 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
                 }
             }
         } else {
-            if (t + 1 < T && !(a.dbg & 1)) stage_ops(t + 1, cin, pn, cnn);
-            if (t < T && rem == 0 && !(a.dbg & 16)) {             // first step of chunk ci: its x tile
+            if (t + 1 < T) stage_ops(t + 1, cin, pn, cnn);
+            if (t < T && rem == 0) {             // first step of chunk ci: its x tile
                 stage_rows<BM>(x_s + (ci & 1) * XS, xg, a.ldx, m0, a.M, ci * IC, a.I, IC, ICP, pt);
             }
             if (RBF && t < T && cn == 0) {                        // first step of (ci, p): its u tile
@@ -1830,7 +1827,7 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
             if (t >= 2) {
                 const int rem2 = p2 * ncn + cn2;
                 const bool ended2 = SHARED ? (rem2 == spc - 1) : (cn2 == ncn - 1);
-                if (ended2 && !(a.dbg & 16)) {
+                if (ended2) {
                     if (RBF && a.du)
                         write_rows(du_s + ((ci2 * nshare + p2) & 1) * XS, a.du + (long long)(p2 * a.xmod + gx) * a.I, (int)a.ldu,
                                    ci2 * IC, false);
@@ -1841,12 +1838,12 @@ __global__ __launch_bounds__(NTHR) void kan_bwd_input_kernel(const LayerArgs a) 
             if (t >= 1 && t - 1 < T) {
                 const int rem1 = p1 * ncn + cn1;
                 const bool ended1 = SHARED ? (rem1 == spc - 1) : (cn1 == ncn - 1);
-                if (ended1 && !(a.dbg & 2)) chain_rule(ci1, p1);
+                if (ended1) chain_rule(ci1, p1);
             }
         }
         if (ends) {
             __syncthreads();                                      // producers are done reading dA_s
-            if (consumer && !(a.dbg & 64)) {
+            if (consumer) {
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -2325,8 +2322,6 @@ LayerArgs base_args(const kanvit_layer_desc* d) {
     a.K = d->I * a.GP;
     a.rbf_inv_h = d->rbf_inv_h;
     a.flags = d->flags;
-    const char* dbg = getenv("KANVIT_DBG");
-    a.dbg = dbg ? atoi(dbg) : 0;
     return a;
 }
 
@@ -2356,11 +2351,7 @@ template <int FAM, int NT, int NSH, bool FAST>
 int launch_fwd(const LayerArgs& a, hipStream_t st) {
     constexpr int BN = 32 * NT;
     const size_t lds = fwd_lds<FAM>(a.IC, a.GP, NT, NSH);
-    static bool attr_done = false;   // benign race: idempotent
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(kan_fwd_kernel<FAM, NT, NSH, FAST>, 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, kan_fwd_kernel<FAM, NT, NSH, FAST>);
     dim3 grid((unsigned)((a.groups / NSH) * ((a.O + BN - 1) / BN)), (unsigned)((a.M + BM - 1) / BM), 1);
     hipLaunchKernelGGL((kan_fwd_kernel<FAM, NT, NSH, FAST>), grid, dim3(NTHR), lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_kernel");
@@ -2381,7 +2372,7 @@ struct FwdRegBf16Plan {
 
 FwdRegBf16Plan plan_fwd_reg_bf16(const kanvit_layer_desc* d) {
     FwdRegBf16Plan p{};
-    if (getenv("KANVIT_NO_REG")) return p;
+    if (kv_config().no_reg) return p;
     p.gp = gp_of(d);
     const int fam = d->family;
     const bool gp_ok = (fam == KANVIT_LINEAR && p.gp == 1) || (fam == KANVIT_CHEBY && p.gp == 5) ||
@@ -2414,12 +2405,8 @@ int launch_fwd_reg_bf16(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t
     if constexpr (ICH == 8 && (FAM == KV_LINEAR || FAM == KV_CHEBY)) {     // the families whose basis fragments fit the register file
         const size_t wlds = (size_t)p.nch * p.vs * 2 * 32 * NT * NSH * 16 + sizeof(float) * 32 * NT * NSH;
         const int gx = (a.groups / NSH) * (a.O / (32 * NT));
-        if (wlds <= 150 * 1024 && p.nch == 4 && a.M >= 4096 && gx <= N_CU && !((uintptr_t)a.y & 15) && !getenv("KANVIT_NO_WS")) {
-            static bool ws_attr_done = false;
-            if (!ws_attr_done) {
-                KV_HIP_CHECK(kv_allow_lds((kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>), 160 * 1024));
-                ws_attr_done = true;
-            }
+        if (wlds <= 150 * 1024 && p.nch == 4 && a.M >= 4096 && gx <= N_CU && !((uintptr_t)a.y & 15) && !kv_config().no_ws) {
+            KV_ALLOW_LDS(160 * 1024, (kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>));
             const long long ntiles = (a.M + KV_WS_THREADS / 2 - 1) / (KV_WS_THREADS / 2);
             long long py = N_CU / gx;             // one work-group per CU (the image fills the LDS)
             if (py > ntiles) py = ntiles;
@@ -2429,11 +2416,7 @@ int launch_fwd_reg_bf16(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t
             return 0;
         }
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds((kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>), 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>));
     dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
     hipLaunchKernelGGL((kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>), grid, dim3(256), p.lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_reg_bf16_kernel");
@@ -2487,8 +2470,8 @@ FwdBf16Plan plan_fwd_bf16(const kanvit_layer_desc* d) {
     const int nshare = d->groups / d->x_group_mod;
     const bool shared_fam = kv_share_ok(d->family, d->flags);
     p.nsh = (shared_fam && nshare == 3 && p.nt <= 2) ? 3 : 1;
-    if (getenv("KANVIT_BF16_NSH")) p.nsh = atoi(getenv("KANVIT_BF16_NSH")) == 3 && p.nsh == 3 ? 3 : 1;   // tuning knob
-    const int icmax = getenv("KANVIT_BF16_IC") ? atoi(getenv("KANVIT_BF16_IC")) : 64;                    // tuning knob
+    if (kv_config().bf16_nsh) p.nsh = (kv_config().bf16_nsh == 3 && p.nsh == 3) ? 3 : 1;   // tuning knob
+    const int icmax = kv_config().bf16_ic ? kv_config().bf16_ic : 64;                    // tuning knob
     const int rbf = d->family == KANVIT_RBF ? 2 : 1;
     for (int ic = 16; ic >= 8; ic >>= 1) {        // largest power-of-two chunk (<= 16: register-staged loads) dividing I
         if (d->I % ic || ic > icmax) continue;
@@ -2511,11 +2494,7 @@ FwdBf16Plan plan_fwd_bf16(const kanvit_layer_desc* d) {
 
 template <int FAM, int NT, int NSH>
 int launch_fwd_bf16(const LayerArgs& a, const FwdBf16Plan& p, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(kan_fwd_bf16_kernel<FAM, NT, NSH>, 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, kan_fwd_bf16_kernel<FAM, NT, NSH>);
     dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
     hipLaunchKernelGGL((kan_fwd_bf16_kernel<FAM, NT, NSH>), grid, dim3(NTHR), p.lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_bf16_kernel");
@@ -2545,11 +2524,7 @@ int dispatch_fwd_bf16(LayerArgs& a, const FwdBf16Plan& p, void* ws, hipStream_t 
 // ---- register-operand forward (fp32 exact) --------------------------------------------------------
 template <int FAM, int NT, int NSH, int ICH>
 int launch_fwd_reg(const LayerArgs& a, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds((kan_fwd_reg_kernel<FAM, NT, NSH, ICH>), 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_kernel<FAM, NT, NSH, ICH>));
     dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
     hipLaunchKernelGGL((kan_fwd_reg_kernel<FAM, NT, NSH, ICH>), grid, dim3(256), lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_reg_kernel");
@@ -2566,7 +2541,7 @@ int launch_fwd_reg_ich(const LayerArgs& a, int ich, size_t lds, hipStream_t st) 
 // returns 1 when the shape is not covered (caller falls back to the LDS-tile kernel), 0 on success, < 0 on error
 template <int FAM>
 int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
-    if (getenv("KANVIT_NO_REG")) return 1;
+    if (kv_config().no_reg) return 1;
     if (FAM == KV_BSPLINE && !((a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3)) return 1;
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     if (a.O % (32 * nt)) return 1;
@@ -2621,7 +2596,7 @@ int dispatch_fwd(LayerArgs& a, hipStream_t st) {
     while (icf * 2 <= ic) icf *= 2;
     const bool fast = (icf >= 8) && (a.I % icf == 0) && (a.O % (32 * nt) == 0) &&
                       ((long long)BM * a.ldx < (1LL << 30)) && ((long long)BM * a.ldy < (1LL << 30)) &&
-                      ((long long)BM * a.ldu < (1LL << 30)) && ((long long)a.K * a.O < (1LL << 30)) && !getenv("KANVIT_NO_FAST");
+                      ((long long)BM * a.ldu < (1LL << 30)) && ((long long)a.K * a.O < (1LL << 30)) && !kv_config().no_fast;
     a.IC = fast ? icf : ic;
     if (share3) {
         if constexpr (kv_shared_basis<FAM>()) {
@@ -2647,11 +2622,7 @@ size_t bwd_input_lds(int ic, int gp, int G, int nshare, int bf_O = 0) {
 template <int FAM, int KT, bool SHARED, bool BF>
 int launch_bwd_input(const LayerArgs& a, hipStream_t st) {
     const size_t lds = bwd_input_lds<FAM>(a.IC, a.GP, a.G, a.groups / a.xmod, BF ? a.O : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds((kan_bwd_input_kernel<FAM, KT, SHARED, BF>), 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, (kan_bwd_input_kernel<FAM, KT, SHARED, BF>));
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
     hipLaunchKernelGGL((kan_bwd_input_kernel<FAM, KT, SHARED, BF>), grid, dim3(NTHR), lds, st, a);
     KV_LAUNCH_CHECK("kan_bwd_input_kernel");
@@ -2681,7 +2652,7 @@ int bwd_input_ic(int I, int gp, int G, int nshare, int bf_O) {
 }
 
 bool bwd_input_bf16_ok(const kanvit_layer_desc* d) {
-    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64) && (d->ldy % 4 == 0) && !getenv("KANVIT_NO_BF16");
+    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64) && (d->ldy % 4 == 0) && !kv_config().no_bf16;
 }
 
 template <int FAM>
@@ -2722,7 +2693,7 @@ int launch_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
 // returns 1 when not covered (fall back to the LDS-tile kernel)
 template <int FAM>
 int try_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
-    if (getenv("KANVIT_NO_REG")) return 1;
+    if (kv_config().no_reg) return 1;
     if constexpr (FAM == KV_LINEAR) { if (a.GP == 1) return launch_bwd_input_reg<FAM, 1, 2>(a, st); }
     if constexpr (FAM == KV_CHEBY) { if (a.GP == 5) return launch_bwd_input_reg<FAM, 5, 5>(a, st); }
     if constexpr (FAM == KV_BSPLINE) {
@@ -2747,7 +2718,7 @@ struct BwdRegBf16Plan {
 
 BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
     BwdRegBf16Plan p{};
-    if (getenv("KANVIT_NO_REG") || getenv("KANVIT_NO_BF16") || !(d->flags & KANVIT_FLAG_BF16_MFMA)) return p;
+    if (kv_config().no_reg || kv_config().no_bf16 || !(d->flags & KANVIT_FLAG_BF16_MFMA)) return p;
     p.gp = gp_of(d);
     const int fam = d->family;
     if (fam == KANVIT_LINEAR && p.gp == 1) p.kt = 2;
@@ -2871,11 +2842,7 @@ int launch_bwd_weight_n(const LayerArgs& a, const BwPlan& p, hipStream_t st) {
     if (lds > 160 * 1024) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: tile does not fit the LDS");
     if (KT * BW_NT * NSH > 4 * ((NSH == 1) ? BW_TPW : 8))
         return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: internal tiling error");
-    static bool attr_done = false;
-    if (!attr_done) {
-        KV_HIP_CHECK(kv_allow_lds(kan_bwd_weight_kernel<FAM, NSH, BF>, 160 * 1024));
-        attr_done = true;
-    }
+    KV_ALLOW_LDS(160 * 1024, kan_bwd_weight_kernel<FAM, NSH, BF>);
     dim3 grid((unsigned)p.nfchunks, (unsigned)p.msplit, (unsigned)((a.groups / NSH) * p.nchunks_n));
     hipLaunchKernelGGL((kan_bwd_weight_kernel<FAM, NSH, BF>), grid, dim3(NTHR), lds, st, a);
     KV_LAUNCH_CHECK("kan_bwd_weight_kernel");
@@ -2903,7 +2870,7 @@ struct BwRegPlan {
 
 BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     BwRegPlan p{};
-    if (getenv("KANVIT_NO_REG") || getenv("KANVIT_NO_REG_BW")) return p;
+    if (kv_config().no_reg || kv_config().no_reg_bw) return p;
     p.njc = 1;
     p.gp = gp_of(d);
     const int fam = d->family;
@@ -2912,7 +2879,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // BSPLINE (GP = 9 -> one column tile per wave): every column-tile wave re-evaluates the spline basis, and measured
     // it loses to the LDS-tile kernel (2.46 vs 1.15 ms on the ViT-B q|k|v launch) -- opt-in only until that is fixed
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 &&
-             getenv("KANVIT_REG_BW_BSPLINE")) p.nt = 2;
+             kv_config().reg_bw_bspline) p.nt = 2;
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
     else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }          // windows of 4 basis functions
@@ -2986,9 +2953,42 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
 
 thread_local char g_kanvit_err[512] = "";
 
+// ---- run-time switches: read once, reported, never consulted through getenv on the launch path ----
+static KvConfig g_kv_config;
+static int g_kv_config_state = 0;      // 0 = not loaded
+static void kv_config_load() {
+    KvConfig c{};
+    auto flag = [](const char* n) { const char* v = getenv(n); return (v && *v && !(v[0] == '0' && !v[1])) ? 1 : 0; };
+    auto num = [](const char* n) { const char* v = getenv(n); return v ? atoi(v) : 0; };
+    c.no_reg = flag("KANVIT_NO_REG");
+    c.no_reg_bw = flag("KANVIT_NO_REG_BW");
+    c.reg_bw_bspline = flag("KANVIT_REG_BW_BSPLINE");
+    c.no_fast = flag("KANVIT_NO_FAST");
+    c.no_ws = flag("KANVIT_NO_WS");
+    c.no_bf16 = flag("KANVIT_NO_BF16");
+    c.attn_v1 = flag("KANVIT_ATTN_V1");
+    c.attn_no_ds = flag("KANVIT_ATTN_NO_DS");
+    c.bf16_nsh = num("KANVIT_BF16_NSH");
+    c.bf16_ic = num("KANVIT_BF16_IC");
+    snprintf(c.text, sizeof(c.text),
+             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_ws=%d no_bf16=%d attn_v1=%d attn_no_ds=%d bf16_nsh=%d bf16_ic=%d",
+             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_ws, c.no_bf16, c.attn_v1, c.attn_no_ds, c.bf16_nsh, c.bf16_ic);
+    g_kv_config = c;
+    __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
+}
+const KvConfig& kv_config() {
+    if (!__atomic_load_n(&g_kv_config_state, __ATOMIC_ACQUIRE)) kv_config_load();     // idempotent: a race loads the same values twice
+    return g_kv_config;
+}
+
 extern "C" {
 
 const char* kanvit_last_error(void) { return g_kanvit_err; }
+const char* kanvit_config(void) { return kv_config().text; }
+int kanvit_config_reload(void) {
+    kv_config_load();
+    return 0;
+}
 int kanvit_abi_version(void) { return KANVIT_ABI_VERSION; }
 int kanvit_device_count(void) {
     int n = 0;
@@ -3023,7 +3023,7 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
     a.bias = bias;
     a.y = y;
     hipStream_t st = (hipStream_t)stream;
-    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !getenv("KANVIT_NO_BF16")) {
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16) {
         const FwdRegBf16Plan pr = plan_fwd_reg_bf16(d);
         if (pr.ok && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)(u ? u : x) | (uintptr_t)(bias ? bias : x)) & 15)) {
             if (!workspace || workspace_bytes < pr.ws_bytes || ((uintptr_t)workspace & 15))
@@ -3153,7 +3153,7 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
         const BwRegPlan pr = plan_bwd_weight_reg(d);
         if (pr.ok) {
             hipStream_t st = (hipStream_t)stream;
-            const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !getenv("KANVIT_NO_BF16");
+            const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
             a.rows_per_split = pr.rows_per_slab;
             a.msplit = pr.slabs;
             a.slab = (pr.slabs > 1) ? (float*)workspace : dw;
@@ -3176,7 +3176,7 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
     a.slab = (p.msplit > 1) ? (float*)workspace : dw;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !getenv("KANVIT_NO_BF16");
+    const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
     switch (d->family) {
         case KANVIT_LINEAR: rc = launch_bwd_weight<KV_LINEAR>(a, p, bf, st); break;
         case KANVIT_CHEBY: rc = launch_bwd_weight<KV_CHEBY>(a, p, bf, st); break;

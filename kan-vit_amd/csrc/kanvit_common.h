@@ -34,12 +34,44 @@ static inline int kv_fail(int code, const char* fmt, ...) {
             return kv_fail(KANVIT_EDEVICE, "launch of %s failed: %s", what, hipGetErrorString(_e)); \
     } while (0)
 
+// Run-time switches of the library (fallback-kernel selection for the parity tests, two tuning knobs).  They are read from
+// the KANVIT_* environment variables ONCE, when the library is first used -- never on the launch path -- and the active set
+// is reported by kanvit_config() so that a measurement can state what it ran.  kanvit_config_reload() re-reads them (tests).
+struct KvConfig {
+    int no_reg;          // KANVIT_NO_REG          register-form KAN kernels off (LDS-tile kernels everywhere)
+    int no_reg_bw;       // KANVIT_NO_REG_BW       register-form weight gradient off
+    int reg_bw_bspline;  // KANVIT_REG_BW_BSPLINE  register-form weight gradient for B-splines on (measured slower)
+    int no_fast;         // KANVIT_NO_FAST         predicate-free variants of the LDS-tile kernels off
+    int no_ws;           // KANVIT_NO_WS           W-stationary bf16 forward off
+    int no_bf16;         // KANVIT_NO_BF16         ignore KANVIT_FLAG_BF16_MFMA (exact fp32 kernels)
+    int attn_v1;         // KANVIT_ATTN_V1         first-form attention kernels
+    int attn_no_ds;      // KANVIT_ATTN_NO_DS      fp32 attention backward without the dS hand-off
+    int bf16_nsh;        // KANVIT_BF16_NSH        LDS-tile bf16 forward: groups per basis tile (tuning)
+    int bf16_ic;         // KANVIT_BF16_IC         LDS-tile bf16 forward: feature chunk cap (tuning)
+    char text[320];
+};
+const KvConfig& kv_config();
+
 template <typename K>
 static inline hipError_t kv_allow_lds(K kernel, size_t bytes) {
     // dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per CU)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)bytes);
 }
+
+// hipFuncSetAttribute is per DEVICE: remember which devices of this process have had the opt-in for this kernel
+// (one 64-bit mask per call site; the call itself is idempotent, so a lost race only repeats it).
+#define KV_ALLOW_LDS(bytes, ...)                                                                  \
+    do {                                                                                          \
+        static unsigned long long kv_mask_ = 0ull;                                                \
+        int kv_dev_ = 0;                                                                          \
+        KV_HIP_CHECK(hipGetDevice(&kv_dev_));                                                     \
+        const unsigned long long kv_bit_ = 1ull << (kv_dev_ & 63);                                \
+        if (!(__atomic_load_n(&kv_mask_, __ATOMIC_RELAXED) & kv_bit_)) {                          \
+            KV_HIP_CHECK(kv_allow_lds(__VA_ARGS__, bytes));                                       \
+            __atomic_fetch_or(&kv_mask_, kv_bit_, __ATOMIC_RELAXED);                              \
+        }                                                                                         \
+    } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

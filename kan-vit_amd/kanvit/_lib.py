@@ -52,6 +52,8 @@ SYMBOLS = {
     "kanvit_abi_version": (C.c_int, []),
     "kanvit_last_error": (C.c_char_p, []),
     "kanvit_device_count": (C.c_int, []),
+    "kanvit_config": (C.c_char_p, []),
+    "kanvit_config_reload": (C.c_int, []),
     "kanvit_layer_fwd_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_bwd_input_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_fwd": (C.c_int, _LAYER_FWD),
@@ -91,10 +93,21 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.kanvit_abi_version() != 2:
+        if handle.kanvit_abi_version() != 3:
             raise KanvitError("libkanvit.so ABI version mismatch")
         _lib = handle
     return _lib
+
+
+def active_config() -> str:
+    """The library's kernel-selection switches as read from KANVIT_* at load ("name=value ..."; all zero = defaults)."""
+    return lib().kanvit_config().decode()
+
+
+def reload_config() -> str:
+    """Re-read the KANVIT_* environment switches (tests switch kernels with it; never needed in production)."""
+    lib().kanvit_config_reload()
+    return active_config()
 
 
 def check(rc, what):

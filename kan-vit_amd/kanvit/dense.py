@@ -109,10 +109,11 @@ def _split3(x: torch.Tensor, pattern: int, bias=None, relu=False, mask=None) -> 
     M, K = x.shape
     out = torch.empty(M, 3 * K, device=x.device, dtype=torch.bfloat16)
     x = x.contiguous()
-    _lib.check(L.kanvit_split3_bf16(M, K, C.c_void_p(x.data_ptr()), None if bias is None else C.c_void_p(bias.data_ptr()),
-                                    int(relu), None if mask is None else C.c_void_p(mask.data_ptr()),
-                                    0 if mask is None else mask.stride(0), C.c_void_p(out.data_ptr()), pattern,
-                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kanvit_split3_bf16")
+    with torch.cuda.device(x.device):              # x's device and its current stream, whatever the ambient device is
+        _lib.check(L.kanvit_split3_bf16(M, K, C.c_void_p(x.data_ptr()), None if bias is None else C.c_void_p(bias.data_ptr()),
+                                        int(relu), None if mask is None else C.c_void_p(mask.data_ptr()),
+                                        0 if mask is None else mask.stride(0), C.c_void_p(out.data_ptr()), pattern,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kanvit_split3_bf16")
     return out
 
 

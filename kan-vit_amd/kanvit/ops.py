@@ -230,6 +230,11 @@ _attn_flags = 0      # set by attention()/attention_packed() from the ambient au
 def _attn_desc(q, k, v, o, causal: bool, scale: float, flags: int = 0) -> AttnDesc:
     B, H, N, D = q.shape
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        if t.dim() != 4 or tuple(t.shape) != (B, H, N, D):
+            # kanvit_attn_desc carries ONE sequence length: a shorter k/v would be read out of bounds, a longer one silently
+            # truncated.  The reference's FlashAttentionFunction accepts q_len != k_len (utils.py:150-160); this path does not.
+            raise KanvitError(f"attention: {n} has shape {tuple(t.shape)}, expected {(B, H, N, D)} "
+                              "(self-attention only: q, k, v and o must agree in batch, heads, length and head size)")
         if t.stride(3) != 1:
             raise KanvitError(f"{n}: innermost dimension must be contiguous")
     return AttnDesc(B, H, N, D, int(bool(causal)), float(scale), int(flags), 0,
@@ -354,8 +359,9 @@ class _AddLayerNormFn(torch.autograd.Function):
         mean = torch.empty(M, device=x.device, dtype=torch.float32)
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
         g, b = gamma.contiguous(), beta.contiguous()
-        check(L.kanvit_addln_fwd(M, D, float(eps), _ptr(x2), _ptr(d2), _ptr(g), _ptr(b), _ptr(s) if d2 is not None else None,
-                                 _ptr(y), _ptr(mean), _ptr(rstd), _stream()), "kanvit_addln_fwd")
+        with torch.cuda.device(x.device):          # launch on x's device and ITS current stream, whatever the ambient device is
+            check(L.kanvit_addln_fwd(M, D, float(eps), _ptr(x2), _ptr(d2), _ptr(g), _ptr(b), _ptr(s) if d2 is not None else None,
+                                     _ptr(y), _ptr(mean), _ptr(rstd), _stream()), "kanvit_addln_fwd")
         ctx.save_for_backward(s, g, mean, rstd)
         ctx.has_delta = d2 is not None
         ctx.shape = x.shape
@@ -374,8 +380,9 @@ class _AddLayerNormFn(torch.autograd.Function):
         db = torch.empty(D, device=s.device, dtype=torch.float32)
         nbytes = int(L.kanvit_addln_bwd_workspace(M, D))
         ws = _workspace(nbytes, s.device)
-        check(L.kanvit_addln_bwd(M, D, _ptr(s), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(gy2), _ptr(gs2), _ptr(dx), _ptr(dg), _ptr(db),
-                                 _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_addln_bwd")
+        with torch.cuda.device(s.device):
+            check(L.kanvit_addln_bwd(M, D, _ptr(s), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(gy2), _ptr(gs2), _ptr(dx), _ptr(dg), _ptr(db),
+                                     _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_addln_bwd")
         dx = dx.view(ctx.shape)
         return dx, (dx if ctx.has_delta else None), dg, db, None
 

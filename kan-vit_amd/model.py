@@ -65,9 +65,26 @@ def _patch_embedding(kind, in_dim, d):
     raise ValueError(f"Unknown transformer type: {kind}")
 
 
+def split_types(kind: str):
+    """'sine' -> ['sine'];  'sine,fourier' (or 'sine+fourier') -> ['sine', 'fourier']: a per-block list of layer types.
+    The reference takes ONE global string (model.py:67-80); the list form is the build-only extension of SURVEY.md section
+    8(d) cfg5 / BASELINE.json configs[4] ("SineKAN + FourierKAN mixed blocks"): block l uses types[l % len(types)] for its
+    per-head q|k|v mappings, the patch embedding uses types[0].  Parameter names and shapes per block are exactly those of the
+    single-type model of that block's type, so a mixed model's state_dict is a block-wise splice of reference state_dicts."""
+    kinds = [k.strip() for k in kind.replace("+", ",").split(",") if k.strip()]
+    if not kinds:
+        raise ValueError(f"Unknown transformer type: {kind}")
+    if len(kinds) > 1 and any(k in ("flash-attn",) for k in kinds):
+        raise ValueError("'flash-attn' stacks bare FlashAttention modules (model.py:113-117) and cannot be mixed per block")
+    return kinds
+
+
 class VisionTransformer(nn.Module):
     def __init__(self, chw, n_patches=7, n_blocks=4, d_hidden=64, n_heads=2, out_d=10, type: str = "vanilla"):
         super().__init__()
+        kinds = split_types(type)
+        self.block_types = [kinds[l % len(kinds)] for l in range(n_blocks)]
+        type = kinds[0]                      # the patch embedding (and the flash-attn switch) follow the first entry
         self.chw = chw
         self.n_patches = n_patches
         self.n_blocks = n_blocks
@@ -86,7 +103,7 @@ class VisionTransformer(nn.Module):
             self.blocks = nn.ModuleList([FlashAttention(dim=d_hidden, heads=n_heads) for _ in range(n_blocks)])
         else:
             self.blocks = nn.ModuleList([TransformerBlock(d_hidden, n_heads, feedforward_dim=4 * d_hidden,
-                                                          attn_type=type) for _ in range(n_blocks)])
+                                                          attn_type=self.block_types[l]) for l in range(n_blocks)])
         self.mlp_head = nn.Sequential(nn.LayerNorm(d_hidden), nn.Linear(d_hidden, out_d))
 
     def patchify(self, images, n_patches):

@@ -34,8 +34,11 @@ class FlashAttentionFunction(Function):
     def forward(ctx, q, k, v, mask, causal, q_bucket_size, k_bucket_size):
         if mask is not None:
             raise NotImplementedError("key-padding masks are not implemented in the HIP attention kernel")
-        if q.shape[-2] != k.shape[-2] and causal:
-            raise NotImplementedError("causal attention with different q / k lengths")
+        if tuple(k.shape) != tuple(q.shape) or tuple(v.shape) != tuple(q.shape):
+            # the reference tiles over independent q / k lengths (utils.py:150-160); the HIP kernel holds one head of ONE
+            # length in a work-group, so cross-attention (FlashAttention(context=...)) is rejected instead of mis-read
+            raise NotImplementedError(f"q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)}: the HIP attention kernel "
+                                      "needs q, k and v of one shape (self-attention)")
         q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
         scale = q.shape[-1] ** -0.5
         o = torch.empty(q.shape, device=q.device, dtype=q.dtype)

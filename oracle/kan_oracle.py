@@ -36,6 +36,41 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 
+# --------------------------------------------------------------------------
+# Operand rounding (checker for the bf16 matrix-core mode of the HIP kernels)
+# --------------------------------------------------------------------------
+# The bf16 mode of the kernels (BASELINE configs[2], [4]) rounds the two operands of every contraction -- the generated
+# basis values Phi(x) and the packed coefficients -- to bf16 and accumulates in fp32.  Inside `operand_rounding(fn)` the
+# layer functions below apply `fn` to exactly those operands, so a float64 evaluation becomes a TIGHT oracle for the
+# bf16 kernels (agreement ~1e-4 instead of the ~1e-2 a comparison with unrounded arithmetic allows).  The reference has
+# no such mode (train.py has no AMP; SURVEY.md section 7 "bf16 parity"); with no rounding installed -- the default --
+# these functions are the plain restatement of the reference.
+_ROUND = None
+
+
+class operand_rounding:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _ROUND
+        self.prev, _ROUND = _ROUND, self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUND
+        _ROUND = self.prev
+        return False
+
+
+def bf16_round(t: Tensor) -> Tensor:
+    """Round to the nearest bf16-representable value (ties to even), keeping the dtype."""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def _rnd(t: Tensor) -> Tensor:
+    return t if _ROUND is None else _ROUND(t)
+
 
 # --------------------------------------------------------------------------
 # a1  ChebyKANLayer.forward          models/cheby.py:36-48
@@ -60,7 +95,7 @@ def cheby_forward(x: Tensor, cheby_coeffs: Tensor, faithful: bool = True) -> Ten
             cols.append(2.0 * t * cols[-1] - cols[-2])
         basis = torch.stack(cols, dim=-1)
     # contraction over (i, d)  (models/cheby.py:44-46)
-    y = basis.reshape(t.shape[0], in_dim * deg1) @ cheby_coeffs.permute(0, 2, 1).reshape(in_dim * deg1, out_dim)
+    y = _rnd(basis).reshape(t.shape[0], in_dim * deg1) @ _rnd(cheby_coeffs).permute(0, 2, 1).reshape(in_dim * deg1, out_dim)
     return y
 
 
@@ -92,7 +127,7 @@ def kanlinear_forward(x: Tensor, base_weight: Tensor, spline_weight: Tensor,
     x2 = x.reshape(-1, in_f)
     w = spline_weight if spline_scaler is None else spline_weight * spline_scaler.unsqueeze(-1)
     bases = bspline_bases(x2, grid, spline_order)
-    y = F.silu(x2) @ base_weight.t() + bases.reshape(x2.shape[0], -1) @ w.reshape(out_f, -1).t()
+    y = _rnd(F.silu(x2)) @ _rnd(base_weight).t() + _rnd(bases).reshape(x2.shape[0], -1) @ _rnd(w).reshape(out_f, -1).t()
     return y.reshape(*lead, out_f)
 
 
@@ -119,9 +154,9 @@ def fastkan_forward(x: Tensor, ln_weight: Tensor, ln_bias: Tensor, rbf_grid: Ten
         denominator = float((rbf_grid[-1] - rbf_grid[0]).item()) / (ng - 1)     # models/fastkan.py:26-27
     u = F.layer_norm(x, (in_f,), ln_weight, ln_bias, 1e-5) if use_layernorm else x
     phi = torch.exp(-(((u.unsqueeze(-1) - rbf_grid) / denominator) ** 2))        # (..., I, ng)
-    y = phi.reshape(*x.shape[:-1], in_f * ng) @ spline_weight.t()
+    y = _rnd(phi).reshape(*x.shape[:-1], in_f * ng) @ _rnd(spline_weight).t()
     if base_weight is not None:
-        y = y + F.silu(x) @ base_weight.t() + base_bias
+        y = y + _rnd(F.silu(x)) @ _rnd(base_weight).t() + base_bias
     return y
 
 
@@ -137,8 +172,8 @@ def fourier_forward(x: Tensor, fouriercoeffs: Tensor, bias: Optional[Tensor]) ->
     x2 = x.reshape(-1, in_f)
     k = torch.arange(1, g + 1, dtype=x.dtype)
     ang = x2.unsqueeze(-1) * k                                   # (M, I, G)
-    y = torch.cos(ang).reshape(x2.shape[0], -1) @ fouriercoeffs[0].reshape(out_f, -1).t()
-    y = y + torch.sin(ang).reshape(x2.shape[0], -1) @ fouriercoeffs[1].reshape(out_f, -1).t()
+    y = _rnd(torch.cos(ang)).reshape(x2.shape[0], -1) @ _rnd(fouriercoeffs[0]).reshape(out_f, -1).t()
+    y = y + _rnd(torch.sin(ang)).reshape(x2.shape[0], -1) @ _rnd(fouriercoeffs[1]).reshape(out_f, -1).t()
     if bias is not None:
         y = y + bias
     return y.reshape(*lead, out_f)
@@ -167,7 +202,7 @@ def sine_forward(x: Tensor, amplitudes: Tensor, freq: Tensor, phase: Tensor, bia
     lead = x.shape[:-1]
     x2 = x.reshape(-1, in_f)
     s = torch.sin(x2.reshape(-1, in_f, 1) * freq.reshape(1, 1, g) + phase.reshape(1, in_f, g))
-    y = s.reshape(x2.shape[0], -1) @ amplitudes.reshape(out_f, -1).t()
+    y = _rnd(s).reshape(x2.shape[0], -1) @ _rnd(amplitudes).reshape(out_f, -1).t()
     if bias is not None:
         y = y + bias
     return y.reshape(*lead, out_f)
@@ -209,7 +244,9 @@ def layer_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, cheby_keep_2d: 
         return fourier_forward(x, g("fouriercoeffs"), sd.get(prefix + "bias"))
     if kind == "sine":
         return sine_forward(x, g("amplitudes"), g("freq"), g("phase"), sd.get(prefix + "bias"))
-    return F.linear(x, g("weight"), sd.get(prefix + "bias"))
+    y = _rnd(x) @ _rnd(g("weight")).t()                  # nn.Linear (attention.py:136-142)
+    b = sd.get(prefix + "bias")
+    return y if b is None else y + b
 
 
 # --------------------------------------------------------------------------

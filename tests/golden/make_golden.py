@@ -151,6 +151,62 @@ def gen_msa():
     print("msa done")
 
 
+def gen_msa_big():
+    """The headline head geometry: MSA(128, 2) -> dh = 64, N = 197 (two 32-feature chunks per head, the register-form
+    kernels with 2 heads sharing a launch); parameters rounded to bf16-representable values so they store in 2 bytes."""
+    blob = {}
+    for t in ["vanilla", "cheby", "fast", "efficientkan", "sine"]:
+        torch.manual_seed(17)
+        msa = MSA(128, 2, type=t)
+        with torch.no_grad():
+            for prm in msa.parameters():
+                prm.copy_(to_bf16_exact(prm))
+        x = torch.randn(2, 197, 128, generator=torch.Generator().manual_seed(23)).requires_grad_(True)
+        y = msa(x)
+        wgt = torch.sin(torch.arange(y.numel(), dtype=torch.float32) * 0.37).reshape(y.shape)
+        (y * wgt).sum().backward()
+        p = t + "."
+        blob[p + "x"], blob[p + "y"], blob[p + "grad_x"], blob[p + "wgt"] = npy(x), npy(y), npy(x.grad), npy(wgt)
+        for k, v in msa.state_dict().items():
+            if v.dtype == torch.float32 and not k.endswith(("grid", "phase")):
+                blob[p + "sdbf16." + k] = bf16_bits(v)
+            else:
+                blob[p + "sd." + k] = npy(v)
+        for k, v in msa.named_parameters():
+            if v.grad is not None:
+                blob[p + "grad." + k] = npy(v.grad)
+    np.savez_compressed(os.path.join(OUT, "msa197.npz"), **blob)
+    print("msa197 done")
+
+
+def gen_metrics():
+    """Output of the reference's reporting helpers (utils.py:13-47, 79-94): the text save_metrics writes (train block with
+    flag 0, test block with flag 1) and calculate_metrics on a fixed 300-sample, 100-class input."""
+    import tempfile
+    import utils as ref_utils
+    blob = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)                                   # the reference creates ./logs unconditionally (utils.py:79)
+        try:
+            fn = os.path.join(td, "m.txt")
+            ref_utils.save_metrics(fn, 20, "Train", 1.23456789, 0.5, 0.25, 0.125, 0.0625, 0)
+            ref_utils.save_metrics(fn, 20, "Test", 4.60517, 0.01, 0.0123456, 0.99995, 0.5, 1)
+            blob["save_metrics_text"] = np.frombuffer(open(fn, "rb").read(), dtype=np.uint8)
+        finally:
+            os.chdir(cwd)
+    g = torch.Generator().manual_seed(9)
+    y_true = (torch.arange(300) % 100).numpy()
+    proba = torch.softmax(2.0 * torch.randn(300, 100, generator=g), dim=1)
+    proba[torch.arange(0, 300, 3), torch.arange(0, 300, 3) % 100] += 1.0          # a third of the samples classified right
+    proba = (proba / proba.sum(1, keepdim=True)).numpy()
+    y_pred = proba.argmax(1)
+    blob["cm.y_true"], blob["cm.y_pred"], blob["cm.proba"] = y_true, y_pred, proba.astype(np.float32)
+    blob["cm.out"] = np.array(ref_utils.calculate_metrics(list(y_true), list(y_pred), list(proba.astype(np.float32))), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **blob)
+    print("metrics done", blob["cm.out"])
+
+
 def gen_flash():
     g = torch.Generator().manual_seed(5)
     q, k, v = (torch.randn(1, 3, 197, 64, generator=g).requires_grad_(True) for _ in range(3))
@@ -280,8 +336,9 @@ def gen_misc():
 
 
 if __name__ == "__main__":
-    gen_misc()
-    gen_layers()
-    gen_msa()
-    gen_flash()
-    gen_models()
+    only = set(sys.argv[1:])                   # e.g. `make_golden.py msa197 metrics` regenerates just those files
+    gens = {"misc": gen_misc, "layers": gen_layers, "msa": gen_msa, "msa197": gen_msa_big, "metrics": gen_metrics,
+            "flash": gen_flash, "models": gen_models}
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn()

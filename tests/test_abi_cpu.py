@@ -50,7 +50,7 @@ def test_descriptor_layout_and_errors(lib):
     from kanvit import _lib
     assert ctypes.sizeof(_lib.LayerDesc) == 10 * 4 + 5 * 8
     assert ctypes.sizeof(_lib.AttnDesc) == 8 * 4 + 12 * 8
-    assert lib.kanvit_abi_version() == 2
+    assert lib.kanvit_abi_version() == 3
     d = _lib.LayerDesc(family=99, groups=1, x_group_mod=1, I=4, O=3, G=1, M=6, ldx=4, ldy=3)
     rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
     assert rc == -22 and b"family" in lib.kanvit_last_error()
@@ -83,6 +83,19 @@ def test_descriptor_layout_and_errors(lib):
     a.flags = 1                                   # bf16 matrix-core mode keeps the recompute kernels: no spill
     assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta
     a.flags = 0
+
+
+def test_switches_are_read_once_and_reported(lib, monkeypatch):
+    """KANVIT_* switches: read at load, not per launch; kanvit_config() reports them; only an explicit reload re-reads."""
+    from kanvit import _lib
+    base = _lib.reload_config()
+    assert "no_reg=0" in base and "no_bf16=0" in base and "attn_v1=0" in base
+    monkeypatch.setenv("KANVIT_NO_REG", "1")
+    assert _lib.active_config() == base                       # a changed environment alone changes nothing
+    assert "no_reg=1" in _lib.reload_config()
+    monkeypatch.delenv("KANVIT_NO_REG")
+    assert _lib.reload_config() == base
+    assert "dbg" not in base.lower()                          # the ablation mask of round 1 is gone from the shipped library
 
 
 def test_no_cpu_fallback():

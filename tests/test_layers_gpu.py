@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 FAMS = ["cheby", "efficientkan", "fast", "fourier", "sine"]
 FWD_TOL = 2e-5
-GRAD_TOL = 3e-4
+GRAD_TOL = 1e-4       # BASELINE.json north_star: within 1e-4 (normwise, relative to the largest reference entry)
 
 
 def make_layer(fam, i, o, big):
@@ -193,7 +193,7 @@ def test_bf16_weight_stationary_forward_matches_tile_kernel(fam, monkeypatch):
     flipped product, stores from accumulators).  Same bf16 operand rounding as the per-tile kernel, so the two must agree
     to fp32 accumulation-order noise; a ragged last row tile (M % 256 != 0) and the bias path (vanilla) are included."""
     from attention import MSA
-    from kanvit import grouped
+    from kanvit import _lib, grouped
     torch.manual_seed(11)
     msa = MSA(256, 4, type=fam).to(DEV)
     x = torch.randn(4096 + 129, 256, device=DEV)
@@ -201,8 +201,12 @@ def test_bf16_weight_stationary_forward_matches_tile_kernel(fam, monkeypatch):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ws = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
         monkeypatch.setenv("KANVIT_NO_WS", "1")
-        tile = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
-        monkeypatch.delenv("KANVIT_NO_WS")
+        _lib.reload_config()
+        try:
+            tile = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+        finally:
+            monkeypatch.delenv("KANVIT_NO_WS")
+            _lib.reload_config()
     scale = float(exact.abs().max())
     assert float((ws - tile).abs().max()) / scale < 1e-5, fam
     err = float((ws - exact).abs().max()) / scale
@@ -215,7 +219,7 @@ def test_weight_gradient_kernels_agree_and_are_deterministic(fam, amp, monkeypat
     """The streaming register-form weight-gradient kernel and the LDS-tile kernel compute the same sums (same operand rounding,
     fp32 accumulation in a different order), and each is bitwise reproducible run to run (slabs + ordered reduce, no atomics)."""
     from attention import MSA
-    from kanvit import grouped
+    from kanvit import _lib, grouped
     torch.manual_seed(4)
     msa = MSA(256, 4, type=fam).to(DEV)
     x = torch.randn(4 * 197 + 5, 256, device=DEV, requires_grad=True)
@@ -232,7 +236,12 @@ def test_weight_gradient_kernels_agree_and_are_deterministic(fam, amp, monkeypat
     reg = [grads() for _ in range(3)]
     assert all(torch.equal(reg[0], r) for r in reg[1:])
     monkeypatch.setenv("KANVIT_NO_REG_BW", "1")
-    tile = [grads() for _ in range(2)]
+    _lib.reload_config()
+    try:
+        tile = [grads() for _ in range(2)]
+    finally:
+        monkeypatch.delenv("KANVIT_NO_REG_BW")
+        _lib.reload_config()
     assert torch.equal(tile[0], tile[1])
     assert float((reg[0] - tile[0]).abs().max()) / float(tile[0].abs().max()) < 1e-5
 

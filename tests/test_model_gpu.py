@@ -23,10 +23,10 @@ def test_msa_against_reference(t):
     y = msa(x)
     (y * torch.linspace(-1, 1, y.numel(), device=DEV).reshape(y.shape)).sum().backward()
     assert max_err(y.cpu(), T(blob[p + "y"])) < 1e-5
-    assert rel_err(x.grad.cpu(), T(blob[p + "grad_x"])) < 3e-4
+    assert rel_err(x.grad.cpu(), T(blob[p + "grad_x"])) < 1e-4
     got = {k: v.grad.cpu() for k, v in msa.named_parameters() if v.grad is not None}
     for k, g in grads_from(blob, p).items():
-        assert close(got[k], g, rtol=3e-4, atol=5e-6), (k, rel_err(got[k], g))
+        assert close(got[k], g, rtol=1e-4, atol=5e-6), (k, rel_err(got[k], g))
 
 
 def build(blob, t):
@@ -51,9 +51,9 @@ def test_model_logits_loss_grads(geom, t):
     named = dict(m.named_parameters())
     for n, gn in zip([str(s) for s in blob["grad_names"]], blob["grad_norms"]):
         mine = float(named[n].grad.double().norm())
-        assert abs(mine - gn) <= 5e-4 * max(gn, 1e-3) + 1e-6, (n, mine, gn)
+        assert abs(mine - gn) <= 1e-4 * max(gn, 1e-3) + 1e-6, (n, mine, gn)
     for n, g in grads_from(blob).items():
-        assert rel_err(named[n].grad.cpu(), g) < 1e-3, (n, rel_err(named[n].grad.cpu(), g))
+        assert rel_err(named[n].grad.cpu(), g) < 1e-4, (n, rel_err(named[n].grad.cpu(), g))
 
 
 @pytest.mark.parametrize("t", TYPES)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import kan_oracle as ko
-from tests._util import T, grads_from, load_npz, max_err, rel_err, state_dict_from
+from tests._util import T, close, grads_from, load_npz, max_err, rel_err, state_dict_from
 
 FAMS = ["cheby", "efficientkan", "fast", "fourier", "sine"]
 
@@ -103,6 +103,22 @@ def test_msa(t, loop):
     assert rel_err(x.grad, T(blob[p + "grad_x"])) < 1e-4
     for k, g in grads_from(blob, p).items():
         assert rel_err(params[k].grad, g) < 1e-3, k
+
+
+@pytest.mark.parametrize("t", ["vanilla", "cheby", "fast", "efficientkan", "sine"])
+def test_msa_headline_head_geometry(t):
+    """MSA(128, 2) at N = 197 (dh = 64: the head geometry of the ViT-B / ViT-S headline) from the imported reference."""
+    blob = load_npz("msa197.npz")
+    p = t + "."
+    sd = state_dict_from(blob, p)
+    params = {k: v.clone().requires_grad_(not ko.is_buffer_key(k)) for k, v in sd.items()}
+    x = T(blob[p + "x"]).clone().requires_grad_(True)
+    y = ko.msa_forward(params, "", x, 2)
+    (y * T(blob[p + "wgt"])).sum().backward()
+    assert max_err(y, T(blob[p + "y"])) < 2e-5
+    assert rel_err(x.grad, T(blob[p + "grad_x"])) < 1e-4
+    for k, g in grads_from(blob, p).items():      # the key-bias gradients are mathematically zero (softmax shift invariance)
+        assert close(params[k].grad, g, rtol=1e-3, atol=5e-6), (k, rel_err(params[k].grad, g))
 
 
 def test_flash_attention_function():

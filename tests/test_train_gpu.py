@@ -1,0 +1,96 @@
+"""train.py as a drop-in entry point, on the GPU: `train.main` fed the golden batch and the reference's initial state must
+reproduce the loss trajectory the imported reference produced with the same step order (train.py:31-40) -- eagerly and
+replayed from a HIP graph (--graph); --amp bf16 runs the same entry point on the bf16 matrix cores; the metrics file it
+writes has the reference's format.  Plus the RCCL path of the gradient reducer with one rank (the box has one GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import T, load_npz, state_dict_from
+
+pytestmark = pytest.mark.gpu
+GEOM = ["--synthetic", "--in-chans", "1", "--image-size", "28", "--n-patches", "7", "--n-blocks", "2", "--n-heads", "2",
+        "--d-hidden", "64", "--out-d", "10", "--batch-size", "4"]
+
+
+def _run(t, tmp_path, extra=()):
+    import train
+    blob = load_npz(f"model_T_{t}.npz")
+    x, y = T(blob["x"]), T(blob["labels"])
+    args = train.parse(["--model-type", t, "--epochs", "1", "--steps-per-epoch", "3", "--log-dir", str(tmp_path / "logs"),
+                        "--no-tuned-gemms", *GEOM, *extra])
+    hist = train.main(args, batches=[(x, y)] * 3, init_state=state_dict_from(blob))
+    return blob, hist
+
+
+@pytest.mark.parametrize("t", ["cheby", "fourier"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_train_main_reproduces_the_reference_trajectory(t, graph, tmp_path):
+    blob, hist = _run(t, tmp_path, ("--graph",) if graph else ())
+    assert len(hist["losses"]) == 3
+    assert np.allclose(hist["losses"], blob["adam_losses"], atol=1e-4), (hist["losses"], blob["adam_losses"])
+    m = hist["model"]
+    assert float((m.v_class.detach().cpu() - T(blob["adam_v_class"])).abs().max()) < 1e-4
+    w = dict(m.named_parameters())[str(blob["adam_w_name"])].detach().cpu().reshape(-1)[:8192]
+    assert float((w - T(blob["adam_w"])).abs().max()) < 1e-4
+    # the metrics block of the last epoch, in the reference's format (utils.py:79-94)
+    text = open(hist["metrics_file"]).read()
+    assert re.fullmatch(r"Epoch: 1, Phase: Train\n  Loss: \d+\.\d{4}\n  Accuracy: \d\.\d{4}\n  Balanced Accuracy: \d\.\d{4}\n"
+                        r"  F1 Score: \d\.\d{4}\n  ROC AUC: (nan|\d\.\d{4})\n\n", text), text
+    assert abs(float(text.split("Loss: ")[1].split()[0]) - float(np.mean(blob["adam_losses"]))) < 2e-4
+
+
+def test_train_main_bf16_mode_follows_the_reference_loosely(tmp_path):
+    blob, hist = _run("cheby", tmp_path, ("--amp", "bf16"))
+    assert np.allclose(hist["losses"], blob["adam_losses"], atol=3e-2), (hist["losses"], blob["adam_losses"])
+    assert hist["losses"] != [float(v) for v in blob["adam_losses"]]
+
+
+def test_synthetic_stream_trains_and_is_reproducible(tmp_path):
+    import train
+    outs = []
+    for rep in range(2):
+        args = train.parse(["--model-type", "cheby", "--epochs", "2", "--steps-per-epoch", "4", "--no-step-metrics",
+                            "--log-dir", str(tmp_path / f"l{rep}"), *GEOM])
+        outs.append(train.main(args)["losses"])
+    assert outs[0] == outs[1] and len(outs[0]) == 8                     # same seed, no atomics: bitwise the same run
+    assert all(np.isfinite(outs[0])) and 1.5 < outs[0][0] < 3.5         # ~ln(10) on random labels
+
+
+def test_grad_reducer_over_rccl_single_rank():
+    """GradReducer on the 'nccl' backend (= RCCL): process group with device_id, hook-driven async bucket all-reduces,
+    finish(); with one rank the averaged gradients must equal the plain ones bit for bit."""
+    import socket
+
+    import torch.distributed as dist
+
+    from kanvit import dp as kdp
+    from model import VisionTransformer
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(0)
+        m = VisionTransformer((1, 28, 28), 7, 2, 64, 2, 10, type="cheby").cuda()
+        x = torch.rand(8, 1, 28, 28, device="cuda")
+        y = (torch.arange(8) % 10).cuda()
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        plain = [p.grad.clone() for p in m.parameters()]
+        for p in m.parameters():
+            p.grad = None
+        red = kdp.GradReducer(m.parameters(), bucket_mib=0.25, always_reduce=True)
+        assert red.active and len(red.buckets) > 1
+        red.zero_grad()
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        red.finish()
+        torch.cuda.synchronize()
+        for p, g in zip(m.parameters(), plain):
+            assert torch.equal(p.grad, g)
+            assert any(p.grad.data_ptr() >= b.data_ptr() and p.grad.data_ptr() < b.data_ptr() + b.numel() * 4 for b in red.buckets)
+    finally:
+        dist.destroy_process_group()
