@@ -41,8 +41,9 @@ Tensor = torch.Tensor
 # --------------------------------------------------------------------------
 # The bf16 mode of the kernels (BASELINE configs[2], [4]) rounds the two operands of every contraction -- the generated
 # basis values Phi(x) and the packed coefficients -- to bf16 and accumulates in fp32.  Inside `operand_rounding(fn)` the
-# layer functions below apply `fn` to exactly those operands, so a float64 evaluation becomes a TIGHT oracle for the
-# bf16 kernels (agreement ~1e-4 instead of the ~1e-2 a comparison with unrounded arithmetic allows).  The reference has
+# layer functions below apply `fn` to exactly those operands -- in the forward products AND in the products autograd forms
+# for the backward (_RoundedMM, _RoundedAttention) -- so a float64 evaluation becomes a TIGHT oracle for the bf16 kernels
+# (agreement ~1e-4..1e-3 instead of the ~1e-2, or far worse on cancelling sums, that unrounded arithmetic allows).  The reference has
 # no such mode (train.py has no AMP; SURVEY.md section 7 "bf16 parity"); with no rounding installed -- the default --
 # these functions are the plain restatement of the reference.
 _ROUND = None
@@ -68,8 +69,64 @@ def bf16_round(t: Tensor) -> Tensor:
     return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
 
 
-def _rnd(t: Tensor) -> Tensor:
-    return t if _ROUND is None else _ROUND(t)
+class _RoundedMM(torch.autograd.Function):
+    """a @ b with both operands rounded, and -- as the bf16 kernels do -- the BACKWARD products formed from rounded operands
+    too: dA = r(dOut) r(B)^T (input-gradient kernel: dY and W^T rounded), dB = r(A)^T r(dOut) (weight-gradient kernel: Phi and
+    dY rounded).  Everything else (basis derivatives, bias sums, LayerNorm) stays unrounded, as in the kernels."""
+
+    @staticmethod
+    def forward(ctx, a, b, fn):
+        ctx.fn = fn
+        ctx.save_for_backward(a, b)
+        return fn(a) @ fn(b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        r = ctx.fn
+        return r(g) @ r(b).transpose(-1, -2), r(a).transpose(-1, -2) @ r(g), None
+
+
+def _mm(a: Tensor, b: Tensor) -> Tensor:
+    """The contraction of a layer: plain a @ b, or its operand-rounded form inside `operand_rounding`."""
+    return a @ b if _ROUND is None else _RoundedMM.apply(a, b, _ROUND)
+
+
+class _RoundedAttention(torch.autograd.Function):
+    """softmax(q k^T scale) v with the rounding points of the bf16 attention kernels (csrc/attention.hip):
+    forward   S = r(q) r(k)^T;  p = exp(scale S - max) (fp32, unrounded);  o = r(p) r(v) / sum(p)
+              (first-form kernels, head sizes other than 32 / 64, round the NORMALISED probabilities: `norm_first`)
+    backward  P = exp(scale S - lse), dP = r(do) r(v)^T, delta = rowsum(do * o) (unrounded), dS = P scale (dP - delta);
+              dv = r(P)^T r(do);  dk = r(dS)^T r(q);  dq = r(dS) r(k)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, fn, norm_first):
+        scale = q.shape[-1] ** -0.5
+        s = (fn(q) @ fn(k).transpose(-1, -2)) * scale
+        mx = s.amax(dim=-1, keepdim=True)
+        p = torch.exp(s - mx)
+        l = p.sum(dim=-1, keepdim=True)
+        o = fn(p / l) @ fn(v) if norm_first else (fn(p) @ fn(v)) / l
+        ctx.fn, ctx.scale = fn, scale
+        ctx.save_for_backward(q, k, v, o, (l.log() + mx))
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        r, scale = ctx.fn, ctx.scale
+        p = torch.exp((r(q) @ r(k).transpose(-1, -2)) * scale - lse)
+        dp = r(do) @ r(v).transpose(-1, -2)
+        delta = (do * o).sum(dim=-1, keepdim=True)
+        ds = p * scale * (dp - delta)
+        return r(ds) @ r(k), r(ds).transpose(-1, -2) @ r(q), r(p).transpose(-1, -2) @ r(do), None, None
+
+
+def _attention_core(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+    """softmax(q k^T / sqrt(dh)) v on (..., N, dh) tensors: plain, or with the bf16 kernels' rounding points."""
+    if _ROUND is None:
+        return torch.softmax(q @ k.transpose(-1, -2) / (q.shape[-1] ** 0.5), dim=-1) @ v
+    return _RoundedAttention.apply(q, k, v, _ROUND, q.shape[-1] not in (32, 64))
 
 
 # --------------------------------------------------------------------------
@@ -95,7 +152,7 @@ def cheby_forward(x: Tensor, cheby_coeffs: Tensor, faithful: bool = True) -> Ten
             cols.append(2.0 * t * cols[-1] - cols[-2])
         basis = torch.stack(cols, dim=-1)
     # contraction over (i, d)  (models/cheby.py:44-46)
-    y = _rnd(basis).reshape(t.shape[0], in_dim * deg1) @ _rnd(cheby_coeffs).permute(0, 2, 1).reshape(in_dim * deg1, out_dim)
+    y = _mm(basis.reshape(t.shape[0], in_dim * deg1), cheby_coeffs.permute(0, 2, 1).reshape(in_dim * deg1, out_dim))
     return y
 
 
@@ -127,7 +184,7 @@ def kanlinear_forward(x: Tensor, base_weight: Tensor, spline_weight: Tensor,
     x2 = x.reshape(-1, in_f)
     w = spline_weight if spline_scaler is None else spline_weight * spline_scaler.unsqueeze(-1)
     bases = bspline_bases(x2, grid, spline_order)
-    y = _rnd(F.silu(x2)) @ _rnd(base_weight).t() + _rnd(bases).reshape(x2.shape[0], -1) @ _rnd(w).reshape(out_f, -1).t()
+    y = _mm(F.silu(x2), base_weight.t()) + _mm(bases.reshape(x2.shape[0], -1), w.reshape(out_f, -1).t())
     return y.reshape(*lead, out_f)
 
 
@@ -154,9 +211,9 @@ def fastkan_forward(x: Tensor, ln_weight: Tensor, ln_bias: Tensor, rbf_grid: Ten
         denominator = float((rbf_grid[-1] - rbf_grid[0]).item()) / (ng - 1)     # models/fastkan.py:26-27
     u = F.layer_norm(x, (in_f,), ln_weight, ln_bias, 1e-5) if use_layernorm else x
     phi = torch.exp(-(((u.unsqueeze(-1) - rbf_grid) / denominator) ** 2))        # (..., I, ng)
-    y = _rnd(phi).reshape(*x.shape[:-1], in_f * ng) @ _rnd(spline_weight).t()
+    y = _mm(phi.reshape(*x.shape[:-1], in_f * ng), spline_weight.t())
     if base_weight is not None:
-        y = y + _rnd(F.silu(x)) @ _rnd(base_weight).t() + base_bias
+        y = y + _mm(F.silu(x), base_weight.t()) + base_bias
     return y
 
 
@@ -172,8 +229,8 @@ def fourier_forward(x: Tensor, fouriercoeffs: Tensor, bias: Optional[Tensor]) ->
     x2 = x.reshape(-1, in_f)
     k = torch.arange(1, g + 1, dtype=x.dtype)
     ang = x2.unsqueeze(-1) * k                                   # (M, I, G)
-    y = _rnd(torch.cos(ang)).reshape(x2.shape[0], -1) @ _rnd(fouriercoeffs[0]).reshape(out_f, -1).t()
-    y = y + _rnd(torch.sin(ang)).reshape(x2.shape[0], -1) @ _rnd(fouriercoeffs[1]).reshape(out_f, -1).t()
+    y = _mm(torch.cos(ang).reshape(x2.shape[0], -1), fouriercoeffs[0].reshape(out_f, -1).t())
+    y = y + _mm(torch.sin(ang).reshape(x2.shape[0], -1), fouriercoeffs[1].reshape(out_f, -1).t())
     if bias is not None:
         y = y + bias
     return y.reshape(*lead, out_f)
@@ -202,7 +259,7 @@ def sine_forward(x: Tensor, amplitudes: Tensor, freq: Tensor, phase: Tensor, bia
     lead = x.shape[:-1]
     x2 = x.reshape(-1, in_f)
     s = torch.sin(x2.reshape(-1, in_f, 1) * freq.reshape(1, 1, g) + phase.reshape(1, in_f, g))
-    y = _rnd(s).reshape(x2.shape[0], -1) @ _rnd(amplitudes).reshape(out_f, -1).t()
+    y = _mm(s.reshape(x2.shape[0], -1), amplitudes.reshape(out_f, -1).t())
     if bias is not None:
         y = y + bias
     return y.reshape(*lead, out_f)
@@ -244,7 +301,7 @@ def layer_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, cheby_keep_2d: 
         return fourier_forward(x, g("fouriercoeffs"), sd.get(prefix + "bias"))
     if kind == "sine":
         return sine_forward(x, g("amplitudes"), g("freq"), g("phase"), sd.get(prefix + "bias"))
-    y = _rnd(x) @ _rnd(g("weight")).t()                  # nn.Linear (attention.py:136-142)
+    y = _mm(x, g("weight").t())                          # nn.Linear (attention.py:136-142)
     b = sd.get(prefix + "bias")
     return y if b is None else y + b
 
@@ -261,7 +318,6 @@ def msa_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_heads: int, fai
     batch into the row dimension (identical results)."""
     bsz, n, d = x.shape
     dh = d // n_heads
-    scale = dh ** 0.5
     if faithful_loop:
         outs = []
         for b in range(bsz):
@@ -271,7 +327,7 @@ def msa_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_heads: int, fai
                 q = layer_forward(sd, f"{prefix}q_mappings.{h}.", seq)
                 k = layer_forward(sd, f"{prefix}k_mappings.{h}.", seq)
                 v = layer_forward(sd, f"{prefix}v_mappings.{h}.", seq)
-                heads.append(torch.softmax(q @ k.t() / scale, dim=-1) @ v)
+                heads.append(_attention_core(q, k, v))
             outs.append(torch.cat(heads, dim=1))
         return torch.stack(outs, dim=0)
     heads = []
@@ -280,7 +336,7 @@ def msa_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_heads: int, fai
         q = layer_forward(sd, f"{prefix}q_mappings.{h}.", seq).reshape(bsz, n, dh)
         k = layer_forward(sd, f"{prefix}k_mappings.{h}.", seq).reshape(bsz, n, dh)
         v = layer_forward(sd, f"{prefix}v_mappings.{h}.", seq).reshape(bsz, n, dh)
-        heads.append(torch.softmax(q @ k.transpose(1, 2) / scale, dim=-1) @ v)
+        heads.append(_attention_core(q, k, v))
     return torch.cat(heads, dim=-1)
 
 

@@ -35,8 +35,10 @@ def test_msa_headline_geometry_against_reference(t):
     got = {k: v.grad.cpu() for k, v in msa.named_parameters() if v.grad is not None}
     want = grads_from(blob, p)
     assert set(want) == set(got)
-    for k, g in want.items():      # key-bias gradients are mathematically zero (softmax shift invariance): atol covers them
-        assert close(got[k], g, rtol=TOL, atol=2e-6), (k, rel_err(got[k], g))
+    for k, g in want.items():
+        # key-bias gradients are mathematically zero (softmax shift invariance); the reference's own value is rounding noise
+        # of a few 1e-6 at this loss scale, and so is ours: the absolute term covers them and nothing else
+        assert close(got[k], g, rtol=TOL, atol=1e-5), (k, rel_err(got[k], g))
 
 
 def _oracle_qkv(msa, x2d, w, h):
@@ -108,6 +110,8 @@ def test_full_geometry_block_vs_fp64_oracle(name):
     assert max_err(logits.cpu(), ref) < TOL, (name, max_err(logits.cpu(), ref))
     assert abs(float(loss) - float(ref_loss)) < TOL
     for k, p in m.named_parameters():
+        if not p.requires_grad:               # FastKAN's frozen rbf.grid (models/fastkan.py:22-23)
+            continue
         g = params[k].grad
         assert g is not None and p.grad is not None, k
         assert close(p.grad.cpu(), g, rtol=TOL, atol=2e-7), (name, k, rel_err(p.grad.cpu(), g, floor=1e-6))
