@@ -18,6 +18,8 @@
 // D..32*DT-1 and rows N..NP-1 are zero.
 #include "kanvit_common.h"
 
+#include <type_traits>
+
 #include <stdlib.h>
 
 namespace {
@@ -82,6 +84,7 @@ struct AttnArgs {
     float* ds;        // [B*H][NP][NP] dS = P*scale*(dP - delta), written by attn_bwd_kv2_kernel<.., DSOUT>, read by attn_bwd_dq_kernel
     long long qsb, qsh, qsn, ksb, ksh, ksn, vsb, vsh, vsn, osb, osh, osn;
     int B, H, N, D, causal, nkt, vec;
+    int third;        // backward: the third-form fp32 kernels run (decided once in kanvit_attn_bwd)
     float scale;
 };
 
@@ -513,6 +516,216 @@ __global__ __launch_bounds__(BF ? 256 : 512, 2) void attn_fwd2_kernel(const Attn
             if (hf == 0 && a.lse) a.lse[(long long)bh * N + qrow] = mx * a.scale + logf(sum);
         }
     }
+}
+
+// =============================================================================================
+// forward, third form (exact fp32, D == 32*DT, 16-byte aligned operands): attn_fwd2_kernel's mathematics and tile
+// orientation with
+//   * K and V rows 16-byte aligned in the LDS (row stride D + 4 floats: conflict-free ds_read_b128 with lane = row and
+//     ds_read2_b32 with lane = column; the fill is one ds_write_b128 per float4 instead of four ds_write_b32), S^T = K.Q^T
+//     reading FOUR k-steps of K per LDS instruction;
+//   * the ragged last key tile contributing only its valid keys to O^T (the other probabilities are exactly zero: for
+//     N = 197, 4 of 16 k-steps), masks applied to that tile only (or to every tile under the causal mask), v_exp_f32
+//     directly (arguments are <= 0) instead of the range-checked exp2f;
+//   * work-groups that walk the (batch, head) pairs with stride gridDim.x (one launch-resident round).
+// What the in-kernel phase stamps of the diagnostic build (tools/clock_probe.py, -DKANVIT_CLOCK_PROBE) show for one head at
+// ViT-B size (~90 k cycles on a CU, 2.3 GHz held): the two MFMA phases are half of it, a fifth is WAITING for the K / V rows
+// (nothing else is resident on the CU: a head's fp32 K and V fill the LDS), 7 % waiting for each tile's Q rows, 10 %
+// barriers and LDS fill, 6 % the exponentials.  Hiding the fill behind MFMA work needs 28-56 staging registers per lane
+// next to the 16*NKT scores: at 256 registers hipcc parks them in scratch (which needs the data, so it waits), any
+// exec-masked or run-time-conditional staging load draws s_waitcnt vmcnt(0), and the 4-wave / 512-register form drowns in
+// AGPR <-> VGPR copies of the accumulators (all three measured) -- that is the open item.
+// =============================================================================================
+constexpr int kv_pad4(int d) { return d + 4; }
+constexpr int KV_N_CU = 256;           // MI355X
+// persistent kernels: as many work-groups as are resident at once (LDS-limited), never more than heads
+inline int kv_persistent_grid(int nbh, size_t lds_bytes) {
+    const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+    const int g = kv_config().attn_grid > 0 ? kv_config().attn_grid : KV_N_CU * per_cu;      // KANVIT_ATTN_GRID: tuning knob
+    return nbh < g ? nbh : g;
+}
+
+#ifdef KANVIT_CLOCK_PROBE
+// Diagnostic build only (never shipped: tools/README.md): one work-group in the middle of the grid stamps the shader clock
+// and the 100 MHz real-time counter around its lifetime and around the phases of its wave 0, so the clock the chip holds
+// DURING this kernel inside a real training step and the share of each phase can be read (MI355X_MICROARCH.md, "DVFS
+// give-back" item 6; cdna_hip_programming.md section 7 "In-kernel stamps").  The stamps go to a buffer nothing reads.
+__device__ unsigned long long g_kv_clk[16];
+#define KV_CLK_BEGIN()                                                            \
+    unsigned long long kv_t0 = 0, kv_r0 = 0, kv_tp = 0, kv_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  \
+    const bool kv_stamp = (blockIdx.x == gridDim.x / 2) && threadIdx.x == 0;      \
+    if (kv_stamp) { kv_t0 = kv_tp = __builtin_amdgcn_s_memtime(); kv_r0 = __builtin_amdgcn_s_memrealtime(); }
+#define KV_CLK_PHASE(i)                                                           \
+    if (kv_stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long kv_now = __builtin_amdgcn_s_memtime(); kv_ph[i] += kv_now - kv_tp; kv_tp = kv_now; __builtin_amdgcn_sched_barrier(0); }
+#define KV_CLK_END()                                                              \
+    if (kv_stamp) { g_kv_clk[0] = __builtin_amdgcn_s_memtime() - kv_t0; g_kv_clk[1] = __builtin_amdgcn_s_memrealtime() - kv_r0; \
+                    for (int kv_i = 0; kv_i < 8; ++kv_i) g_kv_clk[2 + kv_i] = kv_ph[kv_i]; }
+#else
+#define KV_CLK_BEGIN()
+#define KV_CLK_PHASE(i)
+#define KV_CLK_END()
+#endif
+
+template <int DT, int NTHR>
+__device__ __forceinline__ void fill_rows_f32(float* __restrict__ dst, const float* __restrict__ src, long long stride_n, int NP, int N,
+                                              int tid) {
+    // dst[NP][32*DT + 4] <- src rows (float4 global loads, four passes in flight, ds_write_b128); rows >= N are zero
+    constexpr int D = 32 * DT, C4 = D / 4, RP = NTHR / C4, KS = kv_pad4(D);
+    const int c4 = (tid % C4) * 4, r0 = tid / C4;
+    for (int rb = 0; rb < NP; rb += 4 * RP) {
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = rb + q * RP + r0;
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (n < N) t = *reinterpret_cast<const f32x4*>(src + (long long)n * stride_n + c4);
+            v[q] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = rb + q * RP + r0;
+            if (n < NP) *reinterpret_cast<f32x4*>(dst + n * KS + c4) = v[q];
+        }
+    }
+}
+
+constexpr int KV_A3_THREADS = 512;     // third-form attention kernels: 8 waves (two per SIMD)
+
+template <int DT, int NKT>
+__global__ __launch_bounds__(KV_A3_THREADS, 2) void attn_fwd3_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, NTHR = KV_A3_THREADS, NW = NTHR / 64, KS = kv_pad4(D);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32, nbh = a.B * a.H;
+    float* K_s = smem;                 // [NP][KS]
+    float* V_s = K_s + NP * KS;        // [NP][KS]
+    KV_CLK_BEGIN()
+    const float sc2 = a.scale * LOG2E;
+    for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {       // persistent over (batch, head) pairs
+        const int bi = bh / a.H, hi = bh - bi * a.H;
+        const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+        float* ob = a.out + bi * a.osb + hi * a.osh;
+        __syncthreads();                   // every wave is done with the previous head's tiles
+        fill_rows_f32<DT, NTHR>(K_s, a.k + bi * a.ksb + hi * a.ksh, a.ksn, NP, N, tid);
+        fill_rows_f32<DT, NTHR>(V_s, a.v + bi * a.vsb + hi * a.vsh, a.vsn, NP, N, tid);
+        __syncthreads();
+        KV_CLK_PHASE(0)
+
+        for (int qt = wave; qt < nkt; qt += NW) {     // no barriers below: a wave without a tile is done
+            __builtin_amdgcn_sched_barrier(0);       // phases are fenced: nothing of the next tile is hoisted into this one's registers
+            const int qrow = qt * 32 + l31;
+            const bool qok = qrow < N;
+            // Q rows as B-operand fragments: lane half hf holds d = 16*DT*hf + s (the contraction order over d is free); rows
+            // past N read row 0 (their outputs are never stored)
+            const float* qp = qb + (long long)(qok ? qrow : 0) * a.qsn + 16 * DT * hf;
+            float qf[16 * DT];
+#pragma unroll
+            for (int s4 = 0; s4 < 4 * DT; ++s4) {
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(qp + 4 * s4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[4 * s4 + e] = u0[e];
+            }
+            KV_CLK_PHASE(2)
+            // ---- S^T tiles (rows = keys, columns = queries): four k-steps of K per ds_read_b128
+            f32x16 sacc[NKT];
+            constexpr int NG = 4 * DT;
+            const float* kp = K_s + l31 * KS + 16 * DT * hf;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
+                if (j < nkt) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const f32x4 ka = *reinterpret_cast<const f32x4*>(kp + j * 32 * KS + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[4 * g + e], sacc[j], 0, 0, 0);
+                    }
+                }
+            }
+            KV_CLK_PHASE(3)
+            // ---- exact softmax over the keys held in this lane and its partner lane (other half).  Keys at or beyond `lim`
+            //      are dead: N, or the query's own position + 1 under the causal mask (utils.py:177-180)
+            __builtin_amdgcn_sched_barrier(0);
+            const int lim = a.causal ? (qrow + 1 < N ? qrow + 1 : N) : N;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if (j < nkt) {
+                    if ((j + 1) * 32 > N || a.causal) {      // wave-uniform: only the ragged last tile, or every tile when causal
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = j * 32 + kv_acc_row(r, hf);
+                            sacc[j][r] = (key >= lim) ? -INFINITY : sacc[j][r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mxs = (mx == -INFINITY) ? 0.0f : mx * sc2;
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if (j < nkt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[j][r] * sc2 - mxs);      // v_exp_f32: arguments <= 0, results in [0, 1]
+                        sacc[j][r] = p;
+                        sum += p;
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            KV_CLK_PHASE(4)
+
+            // ---- O^T[d][query] = sum_key V[key][d] P[key][query]: k-step r of key tile j <-> key j*32 + kv_acc_row(r, hf)
+            //      (both d tiles of a key: one ds_read2_b32); the ragged last key tile contributes only its valid keys
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 oacc[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+            const float* vp = V_s + (4 * hf) * KS + l31;
+            const int nq_last = (N - (nkt - 1) * 32 + 7) >> 3;      // quads of the last key tile that hold a valid key (1..4)
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if (j < nkt) {
+                    const int nq = (j == nkt - 1) ? nq_last : 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q < nq) {
+                            const float* vq = vp + (j * 32 + 8 * q) * KS;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int dt = 0; dt < DT; ++dt)
+                                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[e * KS + dt * 32], sacc[j][4 * q + e], oacc[dt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            KV_CLK_PHASE(5)
+            if (qok) {
+                float* op = ob + (long long)qrow * a.osn + 4 * hf;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {oacc[dt][4 * q] * inv, oacc[dt][4 * q + 1] * inv, oacc[dt][4 * q + 2] * inv, oacc[dt][4 * q + 3] * inv};
+                        *reinterpret_cast<f32x4*>(op + dt * 32 + 8 * q) = v;
+                    }
+                if (hf == 0 && a.lse) a.lse[(long long)bh * N + qrow] = mx * a.scale + logf(sum);
+            }
+            KV_CLK_PHASE(6)
+        }
+        KV_CLK_PHASE(7)
+    }   // heads
+    KV_CLK_END()
 }
 
 // =============================================================================================
@@ -1174,6 +1387,213 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
 }
 
+// =============================================================================================
+// backward, third form (exact fp32, D == 32*DT, aligned operands): the two kernels of the dS hand-off path (key-stationary
+// dK / dV kernel that also stores dS, then dQ = dS.K as one plain product) with the LDS traffic of attn_fwd3_kernel:
+// 16-byte aligned rows, ds_read_b128 for the row-walking operands (four k-steps per instruction), ds_read2_b32 for the
+// column-walking ones, every fragment read one group of MFMAs ahead into a second register set, and the ragged last tile
+// contributing only its valid rows to the products that contract over it.  rowsum(dO*O) (utils.py:286) is formed in the
+// prologue of the first kernel from the dO tile it has just staged (no separate pass over dO and O).
+// =============================================================================================
+template <int DT, int NKT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_kv3_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, KS = kv_pad4(D), NTHR = 512, NW = 8, NG = 4 * DT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32, nbh = a.B * a.H;
+    float* Q_s = smem;                     // [NP][KS]
+    float* dO_s = Q_s + NP * KS;           // [NP][KS]
+    float* ld_s = dO_s + NP * KS;          // [NP][2]: lse * log2(e) (+inf on pad rows: p = exp2(-inf) = 0), rowsum(dO*O)
+    for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {       // persistent over (batch, head) pairs
+    const int bi = bh / a.H, hi = bh - bi * a.H;
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* ob = a.o + bi * a.osb + hi * a.osh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    float* dkb = a.dk + bi * a.ksb + hi * a.ksh;
+    float* dvb = a.dv + bi * a.vsb + hi * a.vsh;
+
+    __syncthreads();                       // every wave is done with the previous head's tiles
+    fill_rows_f32<DT, NTHR>(Q_s, qb, a.qsn, NP, N, tid);
+    fill_rows_f32<DT, NTHR>(dO_s, dob, a.osn, NP, N, tid);
+    __syncthreads();
+    for (int n = tid; n < NP; n += NTHR) {
+        float dl = 0.0f, l2 = INFINITY;
+        if (n < N) {
+            const float* orow = ob + (long long)n * a.osn;
+            const float* drow = dO_s + n * KS;
+#pragma unroll
+            for (int c4 = 0; c4 < D / 4; ++c4) {
+                const f32x4 o4 = *reinterpret_cast<const f32x4*>(orow + 4 * c4);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + 4 * c4);
+                dl += o4[0] * d4[0] + o4[1] * d4[1] + o4[2] * d4[2] + o4[3] * d4[3];
+            }
+            l2 = a.lse_in[(long long)bh * N + n] * LOG2E;
+        }
+        ld_s[2 * n] = l2;
+        ld_s[2 * n + 1] = dl;
+    }
+    __syncthreads();
+    const float sc2 = a.scale * LOG2E;
+    const int nq_last = (N - (nkt - 1) * 32 + 7) >> 3;      // quads of k-steps of the last QUERY tile that hold a valid row
+
+    for (int jt = wave; jt < nkt; jt += NW) {
+        const int key = jt * 32 + l31;
+        const bool key_ok = key < N;
+        float kf[16 * DT], vf[16 * DT];
+        bf16x8_t unused0[1], unused1[1];
+        row_frags<DT, false>(kb + (long long)(key_ok ? key : 0) * a.ksn, key_ok, hf, kf, unused0);
+        row_frags<DT, false>(vb + (long long)(key_ok ? key : 0) * a.vsn, key_ok, hf, vf, unused1);
+
+        f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[dt][r] = 0.0f;
+                dvacc[dt][r] = 0.0f;
+            }
+
+        const float* qrp = Q_s + l31 * KS + 16 * DT * hf;       // row-walking reads (first products)
+        const float* drp = dO_s + l31 * KS + 16 * DT * hf;
+        const float* qcp = Q_s + (4 * hf) * KS + l31;           // column-walking reads (second products)
+        const float* dcp = dO_s + (4 * hf) * KS + l31;
+        for (int qt = 0; qt < nkt; ++qt) {
+            // ---- S[q][key] = Q.K^T and dP[q][key] = dO.V^T, two independent accumulation chains interleaved
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(qrp + qt * 32 * KS + 4 * g);
+                const f32x4 da = *reinterpret_cast<const f32x4*>(drp + qt * 32 * KS + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[4 * g + e], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], vf[4 * g + e], pacc, 0, 0, 0);
+                }
+            }
+            const int nq = (qt == nkt - 1) ? nq_last : 4;
+            // ---- p = exp(s*scale - lse), ds = p * scale * (dp - delta)        (utils.py:278-287)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = qt * 32 + kv_acc_row(r, hf);
+                const float2 ld = *reinterpret_cast<const float2*>(ld_s + 2 * qrow);
+                float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 - ld.x);      // v_exp_f32: exp2(-inf) = 0 on pad rows
+                if (!key_ok || (a.causal && key > qrow)) p = 0.0f;
+                sacc[r] = p;
+                pacc[r] = p * a.scale * (pacc[r] - ld.y);
+            }
+            {       // dS[q][key] for the dQ kernel: row = q (register), 32 consecutive keys per lane half
+                float* dsp = a.ds + ((long long)bh * NP + qt * 32) * NP + jt * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsp[(long long)kv_acc_row(r, hf) * NP] = pacc[r];
+            }
+            // ---- dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]: k-step r <-> query row
+            //      qt*32 + kv_acc_row(r, hf); the ragged last query tile contributes only its valid rows (p = ds = 0 elsewhere)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = (qt * 32 + 8 * q + e) * KS;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dcp[row + dt * 32], sacc[4 * q + e], dvacc[dt], 0, 0, 0);
+                            dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qcp[row + dt * 32], pacc[4 * q + e], dkacc[dt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (key_ok) {
+            store_acc_rows<DT>(dkb + (long long)key * a.ksn, dkacc, hf, 1.0f);
+            store_acc_rows<DT>(dvb + (long long)key * a.vsn, dvacc, hf, 1.0f);
+        }
+    }
+    }   // heads
+}
+
+// dQ from the stored dS: dQ^T[d][q] = sum_key K^T[d][key] dS[q][key].  K in LDS (A operand, lanes walk d: one ds_read2_b32
+// for the two d tiles of a key); the B operand is 16 consecutive keys of the lane's own dS row per key tile (lane half h
+// takes keys 16h + s: float4 loads one key tile ahead).  Fragments are read one quad of k-steps ahead; the ragged last
+// key tile contributes only its valid keys (the dS of the others was stored as exact zeros).
+template <int DT, int NKT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq3_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, KS = kv_pad4(D), NTHR = 512, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32, nbh = a.B * a.H;
+    float* K_s = smem;                    // [NP][KS]
+    for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {       // persistent over (batch, head) pairs
+    const int bi = bh / a.H, hi = bh - bi * a.H;
+    float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
+    __syncthreads();
+    fill_rows_f32<DT, NTHR>(K_s, a.k + bi * a.ksb + hi * a.ksh, a.ksn, NP, N, tid);
+    __syncthreads();
+    const int nlast = N - (nkt - 1) * 32;                         // valid keys of the last tile (1..32)
+    const int nq_last = ((nlast < 16 ? nlast : 16) + 3) >> 2;     // quads of k-steps (lane half 0 holds keys 0..15 of a tile)
+    for (int qt = wave; qt < nkt; qt += NW) {
+        const int qrow = qt * 32 + l31;
+        const float* dsrow = a.ds + ((long long)bh * NP + qrow) * NP + 16 * hf;
+        f32x16 dqacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+        f32x4 nxt[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nxt[e] = *reinterpret_cast<const f32x4*>(dsrow + 4 * e);
+        const float* kcp = K_s + (16 * hf) * KS + l31;
+        float ka[2][4][DT];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) ka[0][e][dt] = kcp[e * KS + dt * 32];
+        for (int j = 0; j < nkt; ++j) {
+            float dsv[16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dsv[4 * e + c] = nxt[e][c];
+            if (j + 1 < nkt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nxt[e] = *reinterpret_cast<const f32x4*>(dsrow + (j + 1) * 32 + 4 * e);
+            }
+            const int nq = (j == nkt - 1) ? nq_last : 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq) {
+                    // next quad: keys 4(q+1) .. of this tile, or the first quad of the next tile (always inside the padded image)
+                    const int nrow = (q + 1 < 4) ? j * 32 + 4 * (q + 1) : (j + 1) * 32;
+                    const bool more = (q + 1 < 4) || (j + 1 < nkt);
+                    if (more) {       // wave-uniform; no select on the loaded value (it would force a wait right here)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int dt = 0; dt < DT; ++dt) ka[(q + 1) & 1][e][dt] = kcp[(nrow + e) * KS + dt * 32];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+                            dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[q & 1][e][dt], dsv[4 * q + e], dqacc[dt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (qrow < N) store_acc_rows<DT>(dqb + (long long)qrow * a.qsn, dqacc, hf, 1.0f);
+    }
+    }   // heads
+}
+
 int check_desc(const kanvit_attn_desc* d, const char* who) {
     if (!d) return kv_fail(KANVIT_EINVAL, "%s: null descriptor", who);
     if (d->B < 0 || d->H < 1 || d->N < 1 || d->D < 1) return kv_fail(KANVIT_EINVAL, "%s: bad sizes", who);
@@ -1224,8 +1644,25 @@ int launch_fwd2(const AttnArgs& a, hipStream_t st) {
     return 0;
 }
 
+template <int DT, int NKT>
+int launch_fwd3(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)2 * a.nkt * 32 * kv_pad4(32 * DT);
+    KV_ALLOW_LDS(160 * 1024, attn_fwd3_kernel<DT, NKT>);
+    hipLaunchKernelGGL((attn_fwd3_kernel<DT, NKT>), dim3((unsigned)kv_persistent_grid(a.B * a.H, lds)), dim3(KV_A3_THREADS), lds, st, a);
+    KV_LAUNCH_CHECK("attn_fwd3_kernel");
+    return 0;
+}
+
 template <int DT, bool BF>
 int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
+    if constexpr (!BF) {
+        if (a.vec && a.D == 32 * DT && ((uintptr_t)a.out % 16 == 0) && !kv_config().attn_v1 && !kv_config().attn_v2) {
+            if (a.nkt <= 1) return launch_fwd3<DT, 1>(a, st);
+            if (a.nkt <= 2) return launch_fwd3<DT, 2>(a, st);
+            if (a.nkt <= 4) return launch_fwd3<DT, 4>(a, st);
+            if (a.nkt <= 7) return launch_fwd3<DT, 7>(a, st);
+        }
+    }
     if (a.vec && a.D == 32 * DT && ((uintptr_t)a.out % 16 == 0) && !kv_config().attn_v1) {
         if (a.nkt <= 1) return launch_fwd2<DT, 1, BF>(a, st);
         if (a.nkt <= 2) return launch_fwd2<DT, 2, BF>(a, st);
@@ -1250,6 +1687,34 @@ int launch_bwd2(const AttnArgs& a, hipStream_t st) {
     KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv2_kernel<DT, BF, false>));
     KV_ALLOW_LDS(160 * 1024, (attn_bwd_q2_kernel<DT, BF>));
     if constexpr (!BF) {
+        if (a.ds && a.third) {      // third form: same dS hand-off, pipelined LDS reads, rowsum(dO*O) in the prologue
+            const size_t lds3 = sizeof(float) * ((size_t)2 * NP * kv_pad4(D) + 2 * (size_t)NP);
+            const size_t ldsq = sizeof(float) * (size_t)NP * kv_pad4(D);
+            const int nbh = a.B * a.H;
+            if (a.nkt <= 2) {
+                KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv3_kernel<DT, 2>));
+                KV_ALLOW_LDS(160 * 1024, (attn_bwd_dq3_kernel<DT, 2>));
+                hipLaunchKernelGGL((attn_bwd_kv3_kernel<DT, 2>), dim3((unsigned)kv_persistent_grid(nbh, lds3)), dim3(512), lds3, st, a);
+                KV_LAUNCH_CHECK("attn_bwd_kv3_kernel");
+                hipLaunchKernelGGL((attn_bwd_dq3_kernel<DT, 2>), dim3((unsigned)kv_persistent_grid(nbh, ldsq)), dim3(512), ldsq, st, a);
+                KV_LAUNCH_CHECK("attn_bwd_dq3_kernel");
+            } else if (a.nkt <= 4) {
+                KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv3_kernel<DT, 4>));
+                KV_ALLOW_LDS(160 * 1024, (attn_bwd_dq3_kernel<DT, 4>));
+                hipLaunchKernelGGL((attn_bwd_kv3_kernel<DT, 4>), dim3((unsigned)kv_persistent_grid(nbh, lds3)), dim3(512), lds3, st, a);
+                KV_LAUNCH_CHECK("attn_bwd_kv3_kernel");
+                hipLaunchKernelGGL((attn_bwd_dq3_kernel<DT, 4>), dim3((unsigned)kv_persistent_grid(nbh, ldsq)), dim3(512), ldsq, st, a);
+                KV_LAUNCH_CHECK("attn_bwd_dq3_kernel");
+            } else {
+                KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv3_kernel<DT, 8>));
+                KV_ALLOW_LDS(160 * 1024, (attn_bwd_dq3_kernel<DT, 8>));
+                hipLaunchKernelGGL((attn_bwd_kv3_kernel<DT, 8>), dim3((unsigned)kv_persistent_grid(nbh, lds3)), dim3(512), lds3, st, a);
+                KV_LAUNCH_CHECK("attn_bwd_kv3_kernel");
+                hipLaunchKernelGGL((attn_bwd_dq3_kernel<DT, 8>), dim3((unsigned)kv_persistent_grid(nbh, ldsq)), dim3(512), ldsq, st, a);
+                KV_LAUNCH_CHECK("attn_bwd_dq3_kernel");
+            }
+            return 0;
+        }
         if (a.ds) {      // dS spill: the key-stationary kernel stores dS, dQ is one plain product (5 MFMA products instead of 7)
             KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv2_kernel<DT, false, true>));
             KV_ALLOW_LDS(160 * 1024, (attn_bwd_dq_kernel<DT>));
@@ -1292,6 +1757,12 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+#ifdef KANVIT_CLOCK_PROBE
+int kanvit_debug_clock(unsigned long long* out) {      // diagnostic build only: {shader cycles, 100 MHz ticks} of the stamped work-group
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kv_clk), 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+}
+#endif
 
 int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, const float* v, float* o, float* lse,
                     void* stream) {
@@ -1342,8 +1813,15 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)d->B * d->H * d->N;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
-    KV_LAUNCH_CHECK("attn_delta_kernel");
+    // the third-form fp32 kernels form rowsum(dO*O) themselves; every other path reads it from the workspace
+    const size_t lds3 = sizeof(float) * ((size_t)2 * a.nkt * 32 * kv_pad4(d->D) + 2 * (size_t)a.nkt * 32);
+    const bool third = a.ds && !kv_config().attn_v2 && !kv_config().attn_v1 && a.vec && (d->D == 32 || d->D == 64) &&
+                       (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)o) % 16 == 0) && lds3 <= 160 * 1024;
+    a.third = third ? 1 : 0;
+    if (!third) {
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
+        KV_LAUNCH_CHECK("attn_delta_kernel");
+    }
     if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !kv_config().no_bf16)
         return d->D <= 32 ? launch_bwd<1, true>(a, st) : launch_bwd<2, true>(a, st);
     return d->D <= 32 ? launch_bwd<1, false>(a, st) : launch_bwd<2, false>(a, st);

@@ -36,7 +36,9 @@ struct BasisArgs {
 // tanh(x) = 1 - 2/(exp(2x)+1): v_exp_f32 + v_rcp_f32, absolute error ~2e-7 over the whole range
 // (saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1).  ocml's tanhf is ~10x the instructions.
 __device__ __forceinline__ float kv_tanh(float x) {
-    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+    // v_rcp_f32 (1 ulp) instead of the correctly rounded quotient: __frcp_rn expands to the ten-instruction IEEE division
+    // sequence, and the matrix pipe waits for every VALU instruction of the fp32 kernels
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
 // sin and cos together, |x| up to ~5e4 with <= 9e-8 absolute error (libm's float sin: 7e-8): k = rint(x * 2/pi), a

@@ -379,8 +379,13 @@ __global__ __launch_bounds__(NTHR) void kan_fwd_kernel(const LayerArgs a) {
 // Epilogue: each wave transposes its 32x32 tiles through a private LDS patch and writes float4 row segments.
 // Requirements (host-checked): O % (32*NT) == 0, I % IC == 0, IC in {8, 4, 2}, 16-byte aligned rows when IC == 8.
 // =============================================================================================
-template <int FAM, int NT, int NSH, int ICH>
-__global__ __launch_bounds__(256) void kan_fwd_reg_kernel(const LayerArgs a) {
+// GPC > 0: the number of basis functions per feature is a compile-time constant (the shapes the reference instantiates).  The
+// chunk body is then fully unrolled and the W fragments are read from LDS ONE K-STEP AHEAD into a second register set, with
+// scheduling fences pinning "reads of step s+1, then MFMAs of step s": an LDS read takes ~100 cycles from issue to use and
+// the round-1 form (read -> s_waitcnt lgkmcnt(0) -> two MFMAs, the same destination registers every time) left the matrix
+// pipe idle for most of that on every second MFMA (59 % busy in the PMC pass).  GPC == 0 keeps the runtime-GP loop.
+template <int FAM, int NT, int NSH, int ICH, int GPC = 0>
+__global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 32 * NT;
     constexpr int WROW = NSH * BN;
@@ -482,6 +487,33 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_kernel(const LayerArgs a) {
             load_x(c + 1);
         }
         const float* wp = W_s + (c & 1) * WSZ + hf * WROW + l31;
+        if constexpr (GPC > 0) {
+            constexpr int VH = ICH * GPC;               // k-steps of this chunk (one generated value per lane and step)
+            constexpr int NTT = NSH * NT;
+            float phi[VH];
+#pragma unroll
+            for (int j = 0; j < ICH; ++j) {
+                BasisGen<FAM> gen;
+                gen.init(b, xc[j], uc[j], c * IC + hf * ICH + j);
+#pragma unroll
+                for (int g = 0; g < GPC; ++g) phi[j * GPC + g] = gen.next(g);
+            }
+            float wa[2][NTT];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) wa[0][t] = wp[t * 32];
+#pragma unroll
+            for (int s2 = 0; s2 < VH; ++s2) {
+                if (s2 + 1 < VH) {
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) wa[(s2 + 1) & 1][t] = wp[(2 * (s2 + 1)) * WROW + t * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // the reads of step s2+1 are issued before the MFMAs of step s2 ...
+#pragma unroll
+                for (int t = 0; t < NTT; ++t)           // flipped product Y^T = W^T . Phi^T: accumulator rows = y columns
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s2 & 1][t], phi[s2], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // ... and nothing else is hoisted across (register budget: 2 waves per SIMD)
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < ICH; ++j) {
             BasisGen<FAM> gen;
@@ -493,6 +525,7 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_kernel(const LayerArgs a) {
                 for (int t = 0; t < NSH * NT; ++t)      // flipped product Y^T = W^T . Phi^T: accumulator rows = y columns
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wj[(2 * g) * WROW + t * 32], av, acc[t], 0, 0, 0);
             }
+        }
         }
         if (c + 1 < nch) store_w((c + 1) & 1);
         __syncthreads();
@@ -654,12 +687,23 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
             load_dy(pn * a.xmod + gx, cnn);
         }
         // contraction over this chunk's 32 dY columns: A = W^T rows (LDS, lane = k row), B = dY of this lane's row
+        // W^T fragments are read ONE k-step ahead into a second register set (same reasoning as the forward kernel: an LDS
+        // read -> wait -> MFMA chain on one register pair leaves the matrix pipe idle for the read latency on every pair)
         const float* wp = W_s + (t & 1) * WSZ + hf * WS + l31;
+        float wa[2][KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) wa[0][kt] = wp[kt * 32];
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
+            if (s2 + 1 < 16) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) wa[(s2 + 1) & 1][kt] = wp[(2 * (s2 + 1)) * WS + kt * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(2 * s2) * WS + kt * 32], dyv[s2], acc[kt], 0, 0, 0);
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s2 & 1][kt], dyv[s2], acc[kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const bool ends = SHARED ? (p == nshare - 1 && cn == ncn - 1) : (cn == ncn - 1);
         if (ends) {
@@ -2522,17 +2566,30 @@ int dispatch_fwd_bf16(LayerArgs& a, const FwdBf16Plan& p, void* ws, hipStream_t 
 }
 
 // ---- register-operand forward (fp32 exact) --------------------------------------------------------
-template <int FAM, int NT, int NSH, int ICH>
+template <int FAM, int NT, int NSH, int ICH, int GPC = 0>
 int launch_fwd_reg(const LayerArgs& a, size_t lds, hipStream_t st) {
-    KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_kernel<FAM, NT, NSH, ICH>));
+    KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_kernel<FAM, NT, NSH, ICH, GPC>));
     dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
-    hipLaunchKernelGGL((kan_fwd_reg_kernel<FAM, NT, NSH, ICH>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((kan_fwd_reg_kernel<FAM, NT, NSH, ICH, GPC>), grid, dim3(256), lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_reg_kernel");
     return 0;
 }
 
 template <int FAM, int NT, int NSH>
 int launch_fwd_reg_ich(const LayerArgs& a, int ich, size_t lds, hipStream_t st) {
+    // compile-time GP instantiations (pipelined chunk body): the basis sizes the reference's call sites build
+    if (!kv_config().no_pipe) {
+        if (ich == 4) {
+            if constexpr (FAM == KV_LINEAR) { if (a.GP == 1) return launch_fwd_reg<FAM, NT, NSH, 4, 1>(a, lds, st); }
+            if constexpr (FAM == KV_CHEBY) { if (a.GP == 5) return launch_fwd_reg<FAM, NT, NSH, 4, 5>(a, lds, st); }
+            if constexpr (FAM == KV_BSPLINE || FAM == KV_RBF) { if (a.GP == 9) return launch_fwd_reg<FAM, NT, NSH, 4, 9>(a, lds, st); }
+            if constexpr (FAM == KV_SINE) { if (a.GP == 4) return launch_fwd_reg<FAM, NT, NSH, 4, 4>(a, lds, st); }
+        }
+        if (ich == 1) {
+            if constexpr (FAM == KV_SINE) { if (a.GP == 28) return launch_fwd_reg<FAM, NT, NSH, 1, 28>(a, lds, st); }
+            if constexpr (FAM == KV_FOURIER) { if (a.GP == 56) return launch_fwd_reg<FAM, NT, NSH, 1, 56>(a, lds, st); }
+        }
+    }
     if (ich == 4) return launch_fwd_reg<FAM, NT, NSH, 4>(a, lds, st);
     if (ich == 2) return launch_fwd_reg<FAM, NT, NSH, 2>(a, lds, st);
     return launch_fwd_reg<FAM, NT, NSH, 1>(a, lds, st);
@@ -2964,15 +3021,18 @@ static void kv_config_load() {
     c.no_reg_bw = flag("KANVIT_NO_REG_BW");
     c.reg_bw_bspline = flag("KANVIT_REG_BW_BSPLINE");
     c.no_fast = flag("KANVIT_NO_FAST");
+    c.no_pipe = flag("KANVIT_NO_PIPE");
     c.no_ws = flag("KANVIT_NO_WS");
     c.no_bf16 = flag("KANVIT_NO_BF16");
     c.attn_v1 = flag("KANVIT_ATTN_V1");
+    c.attn_v2 = flag("KANVIT_ATTN_V2");
     c.attn_no_ds = flag("KANVIT_ATTN_NO_DS");
+    c.attn_grid = num("KANVIT_ATTN_GRID");
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_ws=%d no_bf16=%d attn_v1=%d attn_no_ds=%d bf16_nsh=%d bf16_ic=%d",
-             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_ws, c.no_bf16, c.attn_v1, c.attn_no_ds, c.bf16_nsh, c.bf16_ic);
+             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d",
+             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }

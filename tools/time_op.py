@@ -1,19 +1,25 @@
-"""Time the q|k|v forward (and optionally backward) launches of one MSA block with HIP events, per KANVIT_DBG setting."""
-import sys, os
+"""Time the launches of one MSA block (q|k|v forward, attention, their backwards) with HIP events on the launch stream.
+    python tools/time_op.py [amp] [type] [reps]       (environment switches, e.g. KANVIT_NO_PIPE=1, select fallback kernels)"""
+import os
+import sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'kan-vit_amd'))
 import torch
-from kanvit import ops
+from kanvit import _lib, ops
 from attention import MSA
-amp = len(sys.argv) > 1 and sys.argv[1] == 'amp'
-torch.manual_seed(0)
-m = MSA(768, 12, type='cheby').cuda()
-x = torch.randn(128, 197, 768, device='cuda', requires_grad=True)
-for it in range(11):
-    if it == 3:
-        torch.cuda.synchronize(); ops.timer = ops.KernelTimer()
-    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
-        y = m(x)
-    y.float().square().sum().backward()
-torch.cuda.synchronize()
-for k, v in ops.timer.summary().items():
-    print(f"{os.environ.get('KANVIT_DBG','0'):>3s} {k:24s} {v['avg_ms']*1e3:8.1f} us")
+amp = 'amp' in sys.argv[1:]
+types = [a for a in sys.argv[1:] if a in ('cheby', 'vanilla', 'fast', 'efficientkan', 'sine')] or ['cheby']
+for t in types:
+    torch.manual_seed(0)
+    m = MSA(768, 12, type=t).cuda()
+    x = torch.randn(128, 197, 768, device='cuda', requires_grad=True)
+    for it in range(11):
+        if it == 3:
+            torch.cuda.synchronize()
+            ops.timer = ops.KernelTimer()
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+            y = m(x)
+        y.float().square().sum().backward()
+    torch.cuda.synchronize()
+    for k, v in ops.timer.summary().items():
+        print(f"{t:12s} {k:24s} {v['avg_ms']*1e3:8.1f} us   {v['flops']/v['avg_ms']/1e9:7.1f} TF/s  {v['bytes']/v['avg_ms']/1e6:7.0f} GB/s   [{_lib.active_config()}]")
+    ops.timer = None
