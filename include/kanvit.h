@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KANVIT_ABI_VERSION 3
+#define KANVIT_ABI_VERSION 4
 
 /* error codes */
 #define KANVIT_OK 0
@@ -121,6 +121,28 @@ int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d);
 size_t kanvit_layer_bwd_weight_workspace(const kanvit_layer_desc* d);
 int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const float* u, const float* bparams,
                             const float* dy, float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused patch embedding --------------------------------------
+ * The patch-embedding layer of VisionTransformer.forward (model.py:144-152) with its prologue and epilogue inside the
+ * kernel: the rows of x are gathered straight from the NCHW image batch -- row m = (image m / P, patch m % P),
+ * feature i = (c, iy, ix) of the patch, i.e. model.py:111-126's patchify without the [B, P, I] staging tensor -- and the
+ * output is written as the token sequence the first transformer block reads:
+ *     y[b, prepend_rows + p, :] = layer(patch(b, p)) + pos[prepend_rows + p, :]
+ *     y[b, 0, :]                = cls + pos[0, :]                    (prepend_rows = 1; model.py:150-152)
+ * d describes the layer as for kanvit_layer_fwd with M = B*P rows, I = C*ph*pw, groups = 1; `ldy` is the row stride of y,
+ * whose row count is B*(P + prepend_rows).  pos ([P + prepend_rows][O]) and cls ([O]) may be NULL (nothing added /
+ * prepend_rows = 0).  Runs on the register-form kernels only: returns KANVIT_EINVAL for shapes they do not cover
+ * (O % 32, a feature chunk that does not divide the patch width, FastKAN, which needs u = LayerNorm(x)) -- the caller
+ * then uses patchify + kanvit_layer_fwd.  The weight gradient of the layer is kanvit_layer_bwd_weight on the patch rows. */
+typedef struct kanvit_patch_desc {
+    int32_t C, H, W;         /* image batch is [B][C][H][W], contiguous                                  */
+    int32_t n_patches;       /* patches per side: patch = (H / n_patches) x (W / n_patches) pixels       */
+    int32_t prepend_rows;    /* 0, or 1 = a class-token row in front of every image's patch tokens       */
+    int32_t reserved;
+} kanvit_patch_desc;
+int kanvit_patch_embed_fwd(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* w,
+                           const float* bparams, const float* bias, const float* cls, const float* pos, float* y,
+                           void* stream);
 
 /* ---- multi-head attention core ------------------------------------------------------------
  * o = softmax(q k^T * scale) v per (batch, head); replaces attention.py:199-200 (MSA) and

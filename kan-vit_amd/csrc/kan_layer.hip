@@ -56,6 +56,12 @@ struct LayerArgs {
     int I, O, groups, xmod, G, GP, order, nk, has_base, K, IC, msplit, nchunks_n;
     float rbf_inv_h;
     int flags;
+    // patch gather (kanvit_patch_embed_*): x is an NCHW image batch, row m = (sample m / P, patch m % P), feature i = (c, iy, ix)
+    // of the patch (model.py:111-126); y rows are shifted behind `pg_pre` prepended rows per sample (the class token), `pos`
+    // ([P + pg_pre][O]) is added and the class-token row cls + pos[0] is written by the lanes that own a sample's first patch
+    int pg, pg_C, pg_H, pg_W, pg_n, pg_pre;
+    const float* cls;
+    const float* pos;
 };
 
 __device__ __forceinline__ BasisArgs make_basis(const LayerArgs& a, int g) {
@@ -411,6 +417,27 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
     const bool row_ok = row < mrem;
     const float* xrow = a.x + (m0 + (row_ok ? row : 0)) * a.ldx + xcol + hf * ICH;
     const float* urow = (RBF && a.u) ? a.u + (m0 + (row_ok ? row : 0)) * a.ldu + (long long)gs * a.I + hf * ICH : xrow;
+    // patch gather: the lane's row is a patch of an NCHW image; its ICH features of a chunk are ICH consecutive pixels of one
+    // image line (host-checked: the chunk width divides the patch width), and the chunks are visited in order, so the
+    // position inside the patch advances incrementally: no division in the chunk loop
+    long long yrow = m0 + row;                    // output row of this lane's input row
+    const float* posrow = nullptr;                // position embedding row added to it
+    bool cls_owner = false;                       // this lane also writes its sample's class-token row
+    int pg_ix = 0, pg_iy = 0, pg_off = 0, pg_pw = 0, pg_ph = 0;
+    if (a.pg) {
+        const int P = a.pg_n * a.pg_n;
+        pg_ph = a.pg_H / a.pg_n;
+        pg_pw = a.pg_W / a.pg_n;
+        const long long m = m0 + (row_ok ? row : 0);
+        const long long smp = m / P;
+        const int pidx = (int)(m - smp * P);
+        const int py = pidx / a.pg_n, px = pidx - py * a.pg_n;
+        xrow = a.x + ((smp * a.pg_C) * a.pg_H + (long long)py * pg_ph) * a.pg_W + px * pg_pw;      // patch origin in channel 0
+        pg_ix = pg_off = hf * ICH;
+        yrow = m + (smp + 1) * a.pg_pre;
+        posrow = a.pos ? a.pos + (long long)(pidx + a.pg_pre) * a.O : nullptr;
+        cls_owner = a.pg_pre && a.cls && pidx == 0;
+    }
 
     // W staging: thread -> (LDS row lr = tid / V4 (+ 256/V4 per pass), 4 columns wc); LDS row (s, h) <- global k
     const int wc = (tid & (V4 - 1)) * 4, wr0 = tid / V4;
@@ -451,9 +478,10 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     float xv[ICH], uv[ICH];
-    auto load_x = [&](int c) {
+    auto load_x = [&](int c) {                    // called for c = 0, 1, 2, ... in order
+        const float* xs = a.pg ? xrow + pg_off : xrow + c * IC;
         if constexpr (ICH == 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + c * IC);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xs);
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = v[e];
             if (RBF) {
@@ -464,8 +492,20 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
         } else {
 #pragma unroll
             for (int e = 0; e < ICH; ++e) {
-                xv[e] = xrow[c * IC + e];
+                xv[e] = xs[e];
                 if (RBF) uv[e] = urow[c * IC + e];
+            }
+        }
+        if (a.pg) {                               // next chunk: IC pixels further along the line, then next line, then next channel
+            pg_ix += IC;
+            pg_off += IC;
+            if (pg_ix >= pg_pw) {
+                pg_ix -= pg_pw;
+                pg_off += a.pg_W - pg_pw;
+                if (++pg_iy == pg_ph) {
+                    pg_iy = 0;
+                    pg_off += (a.pg_H - pg_ph) * a.pg_W;
+                }
             }
         }
     };
@@ -538,13 +578,20 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
         for (int t = 0; t < NSH * NT; ++t) {
             const int p = t / NT, nt = t - p * NT;
             const int g = (NSH == 1) ? gs : p * nsets + gs;
-            float* yp = a.y + (m0 + row) * a.ldy + (long long)g * a.O + n0 + nt * 32 + 4 * hf;
-            const float* bp = a.bias ? a.bias + (long long)g * a.O + n0 + nt * 32 + 4 * hf : nullptr;
+            const int col = n0 + nt * 32 + 4 * hf;
+            float* yp = a.y + yrow * a.ldy + (long long)g * a.O + col;
+            const float* bp = a.bias ? a.bias + (long long)g * a.O + col : nullptr;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
                 if (bp) v += *reinterpret_cast<const f32x4*>(bp + 8 * q);
+                if (posrow) v += *reinterpret_cast<const f32x4*>(posrow + col + 8 * q);
                 *reinterpret_cast<f32x4*>(yp + 8 * q) = v;
+                if (cls_owner) {                  // the class-token row of this sample: cls + pos[0] (model.py:150-152), this column tile
+                    f32x4 cv = *reinterpret_cast<const f32x4*>(a.cls + col + 8 * q);
+                    if (a.pos) cv += *reinterpret_cast<const f32x4*>(a.pos + col + 8 * q);
+                    *reinterpret_cast<f32x4*>(yp - a.ldy + 8 * q) = cv;
+                }
             }
         }
     }
@@ -2610,6 +2657,7 @@ int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
     for (int ich = 4; ich >= 1; ich >>= 1) {
         const int ic = 2 * ich, kc = ic * a.GP;
         if (a.I % ic) continue;
+        if (a.pg && (((a.pg_W / a.pg_n) % ic) || (ich == 4 && (a.pg_W & 3)))) continue;     // a chunk is ic consecutive pixels of one line
         if (ich == 4 && ((a.ldx & 3) || (a.I & 3) || ((uintptr_t)a.x & 15) ||
                          (FAM == KV_RBF && a.u && ((a.ldu & 3) || ((uintptr_t)a.u & 15)))))
             continue;
@@ -3106,6 +3154,69 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
 #define KV_CALL(F) dispatch_fwd<F>(a, st)
     KV_FAMILY_SWITCH(d->family, KV_CALL)
 #undef KV_CALL
+}
+
+// ---- fused patch embedding (model.py:111-126 patchify, :144-152 class token + position embedding) ----
+static int patch_validate(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const char* who) {
+    if (!p) return kv_fail(KANVIT_EINVAL, "%s: null patch descriptor", who);
+    if (p->C < 1 || p->H < 1 || p->W < 1 || p->n_patches < 1 || p->H % p->n_patches || p->W % p->n_patches)
+        return kv_fail(KANVIT_EINVAL, "%s: image %dx%dx%d is not divisible into %d x %d patches", who, p->C, p->H, p->W, p->n_patches,
+                       p->n_patches);
+    if (p->prepend_rows != 0 && p->prepend_rows != 1) return kv_fail(KANVIT_EINVAL, "%s: prepend_rows must be 0 or 1", who);
+    const long long P = (long long)p->n_patches * p->n_patches, I = (long long)p->C * (p->H / p->n_patches) * (p->W / p->n_patches);
+    if (d->groups != 1 || d->x_group_mod != 1) return kv_fail(KANVIT_EINVAL, "%s: one layer per launch (groups = 1)", who);
+    if (d->I != I) return kv_fail(KANVIT_EINVAL, "%s: I=%d but a patch has %lld pixels", who, d->I, I);
+    if (d->M % P) return kv_fail(KANVIT_EINVAL, "%s: M=%lld is not a whole number of images (%lld patches each)", who, (long long)d->M, P);
+    if ((long long)p->C * p->H * p->W >= (1LL << 30)) return kv_fail(KANVIT_EINVAL, "%s: image too large for 32-bit offsets", who);
+    if (d->family == KANVIT_RBF) return kv_fail(KANVIT_EINVAL, "%s: FastKAN needs its LayerNorm'ed input u (use kanvit_layer_fwd)", who);
+    return 0;
+}
+
+static void patch_args(LayerArgs& a, const kanvit_patch_desc* p, const float* cls, const float* pos) {
+    a.pg = 1;
+    a.pg_C = p->C;
+    a.pg_H = p->H;
+    a.pg_W = p->W;
+    a.pg_n = p->n_patches;
+    a.pg_pre = p->prepend_rows;
+    a.cls = cls;
+    a.pos = pos;
+    a.ldx = a.I;                         // unused by the gather; keeps the alignment checks of the dispatcher meaningful
+}
+
+int kanvit_patch_embed_fwd(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* w,
+                           const float* bparams, const float* bias, const float* cls, const float* pos, float* y, void* stream) {
+    if (int rc = validate(d, "kanvit_patch_embed_fwd")) return rc;
+    if (int rc = patch_validate(d, p, "kanvit_patch_embed_fwd")) return rc;
+    if (d->M == 0) return 0;
+    if (!images || !w || !y) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_fwd: null images/w/y");
+    if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_fwd: family %d needs bparams", d->family);
+    if (p->prepend_rows && !cls) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_fwd: prepend_rows = 1 needs the class token");
+    if (((uintptr_t)images | (uintptr_t)(cls ? cls : w) | (uintptr_t)(pos ? pos : w)) & 15)
+        return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_fwd: images / cls / pos must be 16-byte aligned");
+    LayerArgs a = base_args(d);
+    a.x = images;
+    a.w = w;
+    a.bp = bparams;
+    a.bias = bias;
+    a.y = y;
+    patch_args(a, p, cls, pos);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 1;
+    if (!kv_config().no_reg) {
+        switch (d->family) {
+            case KANVIT_LINEAR: rc = try_fwd_reg<KV_LINEAR>(a, st); break;
+            case KANVIT_CHEBY: rc = try_fwd_reg<KV_CHEBY>(a, st); break;
+            case KANVIT_BSPLINE: rc = try_fwd_reg<KV_BSPLINE>(a, st); break;
+            case KANVIT_SINE: rc = try_fwd_reg<KV_SINE>(a, st); break;
+            case KANVIT_FOURIER: rc = try_fwd_reg<KV_FOURIER>(a, st); break;
+            default: break;
+        }
+    }
+    if (rc == 1)
+        return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_fwd: shape not covered by the fused kernel (O %% 32, patch width %% chunk, "
+                                      "basis size); use patchify + kanvit_layer_fwd");
+    return rc;
 }
 
 int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d) {

@@ -42,6 +42,11 @@ class AttnDesc(C.Structure):
                 ("o_stride_b", C.c_int64), ("o_stride_h", C.c_int64), ("o_stride_n", C.c_int64)]
 
 
+class PatchDesc(C.Structure):
+    _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_patches", C.c_int32), ("prepend_rows", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 _P = C.c_void_p
 _LAYER_FWD = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]
 _LAYER_BWD_IN = [C.POINTER(LayerDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]
@@ -61,6 +66,7 @@ SYMBOLS = {
     "kanvit_layer_dparam_tiles": (C.c_int64, [C.POINTER(LayerDesc)]),
     "kanvit_layer_bwd_weight_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_bwd_weight": (C.c_int, _LAYER_BWD_W),
+    "kanvit_patch_embed_fwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(PatchDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "kanvit_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
     "kanvit_attn_bwd_workspace": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "kanvit_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -93,7 +99,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.kanvit_abi_version() != 3:
+        if handle.kanvit_abi_version() != 4:
             raise KanvitError("libkanvit.so ABI version mismatch")
         _lib = handle
     return _lib

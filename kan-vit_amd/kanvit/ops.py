@@ -162,51 +162,110 @@ class _KanLayerFn(torch.autograd.Function):
     @staticmethod
     @_bwd
     def backward(ctx, dy):
-        dy = dy.float()
-        cfg: LayerCfg = ctx.cfg
         x, u, w, bparams = ctx.saved_tensors
-        dy = dy.contiguous()
-        M, ldx = x.shape
-        need_x, need_u, need_w, need_bp, need_b = ctx.needs_input_grad[:5]
-        d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, 0 if bparams is None else bparams.shape[1])
-        L = _lib.lib()
-        dx = du = dw = dbp = db = None
-        sine_freq = cfg.family == SINE and need_bp
-        with torch.cuda.device(x.device):
-            if need_x or (need_u and ctx.has_u) or sine_freq:
-                dx = torch.empty_like(x)
-                du_buf = torch.empty(M, cfg.groups * cfg.I, device=x.device, dtype=torch.float32) if cfg.family == RBF else None
-                dpart = None
-                if cfg.family == SINE:
-                    tiles = int(L.kanvit_layer_dparam_tiles(C.byref(d)))
-                    dpart = torch.empty(tiles, cfg.groups, cfg.G, device=x.device, dtype=torch.float32)
-                nb_in = int(L.kanvit_layer_bwd_input_workspace(C.byref(d)))
-                ws_in = _workspace(nb_in, x.device) if nb_in else None
-                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_input" + ("_bf16" if nb_in else ""),
-                            *_layer_cost(cfg, M, "bwd_input")):
-                    check(L.kanvit_layer_bwd_input(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(dy),
-                                                   _ptr(dx), _ptr(du_buf), _ptr(dpart), _ptr(ws_in), C.c_size_t(nb_in),
-                                                   _stream()), "kanvit_layer_bwd_input")
-                if cfg.family == RBF:
-                    if ctx.has_u:
-                        du = du_buf
-                    else:   # u aliased x (no LayerNorm): fold the spline-path gradient back into dx
-                        nshare = cfg.groups // cfg.x_group_mod
-                        dx = dx + du_buf.view(M, nshare, cfg.x_group_mod * cfg.I).sum(1)
-                if sine_freq:
-                    dbp = torch.zeros_like(bparams)
-                    dbp[:, :cfg.G] = dpart.sum(0)
-            if need_w:
-                dw = torch.empty_like(w)
-                nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(d)))
-                ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-                with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_weight" + ("_bf16" if cfg.flags & 1 else ""),
-                            *_layer_cost(cfg, M, "bwd_weight")):
-                    check(L.kanvit_layer_bwd_weight(C.byref(d), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(dw),
-                                                    _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
-            if need_b and ctx.has_bias:
-                db = dy.view(M, cfg.groups, cfg.O).sum(0)
-        return (dx if need_x else None), (du if need_u else None), dw, dbp, db, None
+        return _kan_backward(ctx.cfg, x, u if ctx.has_u else None, w, bparams, dy.float().contiguous(), ctx.needs_input_grad[:5],
+                             ctx.has_u, ctx.has_bias) + (None,)
+
+
+def _kan_backward(cfg: "LayerCfg", x, u, w, bparams, dy, needs, has_u, has_bias):
+    """Gradients of one fused KAN launch w.r.t. (x, u, w, bparams, bias): the C-ABI input-gradient and weight-gradient calls."""
+    M, ldx = x.shape
+    need_x, need_u, need_w, need_bp, need_b = needs
+    d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, 0 if bparams is None else bparams.shape[1])
+    L = _lib.lib()
+    dx = du = dw = dbp = db = None
+    sine_freq = cfg.family == SINE and need_bp
+    with torch.cuda.device(x.device):
+        if need_x or (need_u and has_u) or sine_freq:
+            dx = torch.empty_like(x)
+            du_buf = torch.empty(M, cfg.groups * cfg.I, device=x.device, dtype=torch.float32) if cfg.family == RBF else None
+            dpart = None
+            if cfg.family == SINE:
+                tiles = int(L.kanvit_layer_dparam_tiles(C.byref(d)))
+                dpart = torch.empty(tiles, cfg.groups, cfg.G, device=x.device, dtype=torch.float32)
+            nb_in = int(L.kanvit_layer_bwd_input_workspace(C.byref(d)))
+            ws_in = _workspace(nb_in, x.device) if nb_in else None
+            with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_input" + ("_bf16" if nb_in else ""),
+                        *_layer_cost(cfg, M, "bwd_input")):
+                check(L.kanvit_layer_bwd_input(C.byref(d), _ptr(x), _ptr(u), _ptr(w), _ptr(bparams), _ptr(dy),
+                                               _ptr(dx), _ptr(du_buf), _ptr(dpart), _ptr(ws_in), C.c_size_t(nb_in),
+                                               _stream()), "kanvit_layer_bwd_input")
+            if cfg.family == RBF:
+                if has_u:
+                    du = du_buf
+                else:   # u aliased x (no LayerNorm): fold the spline-path gradient back into dx
+                    nshare = cfg.groups // cfg.x_group_mod
+                    dx = dx + du_buf.view(M, nshare, cfg.x_group_mod * cfg.I).sum(1)
+            if sine_freq:
+                dbp = torch.zeros_like(bparams)
+                dbp[:, :cfg.G] = dpart.sum(0)
+        if need_w:
+            dw = torch.empty_like(w)
+            nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(d)))
+            ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+            with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_weight" + ("_bf16" if cfg.flags & 1 else ""),
+                        *_layer_cost(cfg, M, "bwd_weight")):
+                check(L.kanvit_layer_bwd_weight(C.byref(d), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(dw),
+                                                _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
+        if need_b and has_bias:
+            db = dy.view(M, cfg.groups, cfg.O).sum(0)
+    return (dx if need_x else None), (du if need_u else None), dw, dbp, db
+
+
+def patchify(images: torch.Tensor, n_patches: int) -> torch.Tensor:
+    """(B, C, H, W) -> (B, n^2, C*ph*pw): patches row-major, each flattened in (C, ph, pw) order (model.py:111-126)."""
+    b, c, h, w = images.shape
+    ph, pw = h // n_patches, w // n_patches
+    return images.reshape(b, c, n_patches, ph, n_patches, pw).permute(0, 2, 4, 1, 3, 5).reshape(b, n_patches * n_patches, c * ph * pw)
+
+
+class _PatchEmbedFn(torch.autograd.Function):
+    """images[B, C, H, W] -> tokens[B, P + 1, O] = [cls + pos[0]; layer(patch(b, p)) + pos[1 + p]] in ONE launch (SURVEY.md
+    section 8(f)2): the kernel gathers its rows from the NCHW images (no [B, P, I] staging tensor), adds the position
+    embedding in its epilogue and writes the class-token rows.  Backward: the layer's weight gradient runs on a TRANSIENT
+    patch matrix rebuilt from the saved images (one strided copy, freed right after); d cls = sum_b dy[b, 0]."""
+
+    @staticmethod
+    @_fwd_f32
+    def forward(ctx, images, w, bparams, bias, cls, pos, cfg: LayerCfg, n_patches: int):
+        for n, t in (("images", images), ("w", w), ("bparams", bparams), ("bias", bias), ("cls", cls), ("pos", pos)):
+            _require_gpu_f32(n, t)
+        images = images.contiguous()
+        w = w.contiguous()
+        B, Cc, H, W = images.shape
+        P = n_patches * n_patches
+        y = torch.empty(B, P + 1, cfg.O, device=images.device, dtype=torch.float32)
+        d = _desc(cfg, B * P, cfg.I, cfg.I, cfg.O, 0 if bparams is None else bparams.shape[1])
+        pd = _lib.PatchDesc(Cc, H, W, n_patches, 1, 0)
+        bp = None if bparams is None else bparams.contiguous()
+        bs = None if bias is None else bias.contiguous()
+        cl, po = cls.contiguous(), pos.contiguous()
+        with torch.cuda.device(images.device), _timed("layer_fwd", *_layer_cost(cfg, B * P, "fwd")):
+            check(_lib.lib().kanvit_patch_embed_fwd(C.byref(d), C.byref(pd), _ptr(images), _ptr(w), _ptr(bp), _ptr(bs), _ptr(cl),
+                                                     _ptr(po), _ptr(y), _stream()), "kanvit_patch_embed_fwd")
+        ctx.cfg, ctx.n_patches = cfg, n_patches
+        ctx.has_bp, ctx.has_bias = bparams is not None, bias is not None
+        ctx.save_for_backward(images, w, bp)
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dy):
+        images, w, bparams = ctx.saved_tensors
+        cfg, P = ctx.cfg, ctx.n_patches ** 2
+        dy = dy.float()
+        dcls = dy[:, 0, :].sum(0) if ctx.needs_input_grad[4] else None
+        x = patchify(images, ctx.n_patches).reshape(-1, cfg.I)                 # transient
+        dyt = dy[:, 1:, :].reshape(-1, cfg.O)                                  # transient (contiguous patch-token rows)
+        needs = (False, False, ctx.needs_input_grad[1], ctx.needs_input_grad[2] and ctx.has_bp, ctx.needs_input_grad[3] and ctx.has_bias)
+        _, _, dw, dbp, db = _kan_backward(cfg, x, None, w, bparams, dyt, needs, False, ctx.has_bias)
+        return None, dw, dbp, db, dcls, None, None, None
+
+
+def patch_embed(images, w, cfg: LayerCfg, bparams, bias, cls, pos, n_patches: int) -> torch.Tensor:
+    """Fused patch embedding (see _PatchEmbedFn); w is the packed weight [1, K, O], cls [O], pos [P + 1, O].  Raises
+    KanvitError for shapes the fused kernel does not cover (the caller falls back to patchify + kan_layer)."""
+    return _PatchEmbedFn.apply(images, w, bparams, bias, cls, pos, cfg, n_patches)
 
 
 def kan_layer(x: torch.Tensor, w: torch.Tensor, cfg: LayerCfg, u: Optional[torch.Tensor] = None,

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from attention import MSA, FlashAttention
+from kanvit import ops
 from kanvit.dense import feed_forward
 from kanvit.ops import add_layernorm
 from models.cheby import ChebyKANLayer
@@ -105,6 +106,7 @@ class VisionTransformer(nn.Module):
             self.blocks = nn.ModuleList([TransformerBlock(d_hidden, n_heads, feedforward_dim=4 * d_hidden,
                                                           attn_type=self.block_types[l]) for l in range(n_blocks)])
         self.mlp_head = nn.Sequential(nn.LayerNorm(d_hidden), nn.Linear(d_hidden, out_d))
+        self._fused_embed = None       # None = not tried yet, True / False = the fused patch-embedding kernel covers this model
 
     def patchify(self, images, n_patches):
         """(B, C, H, W) -> (B, n_patches^2, C*ph*pw): patches row-major, each flattened in (C, ph, pw)
@@ -124,16 +126,42 @@ class VisionTransformer(nn.Module):
         even = (torch.arange(d) % 2 == 0).unsqueeze(0)
         return torch.where(even, torch.sin(ang), torch.cos(ang)).to(torch.float32)
 
+    def _embed_fused(self, images):
+        """patchify + patch-embedding KAN layer + class token + position embedding in ONE kernel launch (SURVEY.md section
+        8(f)2; kanvit.ops.patch_embed), or None when the fused kernel does not cover this layer / geometry (then the
+        three-step path below runs: same arithmetic).  The exact fp32 path only: under bf16 autocast the layer runs on
+        the bf16 matrix cores, whose kernels have no gather."""
+        lm = self.linear_mapper
+        if self._fused_embed is False or isinstance(lm, nn.Linear) or not hasattr(lm, "kan_pack") or hasattr(lm, "kan_u"):
+            return None
+        if not images.is_cuda or images.dim() != 4 or torch.is_autocast_enabled("cuda"):
+            return None
+        cfg = lm.kan_cfg()
+        w, bp, bias = lm.kan_pack()
+        try:
+            out = ops.patch_embed(images, w.unsqueeze(0), cfg, None if bp is None else bp.unsqueeze(0),
+                                  None if bias is None else bias.reshape(1, -1), self.v_class.reshape(-1),
+                                  self.pos_embeddings[: self.n_patches ** 2 + 1], self.n_patches)
+        except ops.KanvitError:
+            if self._fused_embed is None:                  # shape not covered: decided once, at the first forward
+                self._fused_embed = False
+                return None
+            raise
+        self._fused_embed = True
+        return out
+
     def forward(self, images):
-        patches = self.patchify(images, self.n_patches)
-        b, p, _ = patches.shape
-        if isinstance(self.linear_mapper, nn.Linear):
-            tokens = self.linear_mapper(patches)
-        else:
-            # ChebyKANLayer returns (B*P, d) like the reference's; restore (B, P, d)
-            tokens = self.linear_mapper(patches).reshape(b, p, self.d_hidden)
-        cls = self.v_class.unsqueeze(0).expand(b, -1, -1)
-        out = torch.cat((cls, tokens), dim=1) + self.pos_embeddings[: p + 1]
+        out = self._embed_fused(images)
+        if out is None:
+            patches = self.patchify(images, self.n_patches)
+            b, p, _ = patches.shape
+            if isinstance(self.linear_mapper, nn.Linear):
+                tokens = self.linear_mapper(patches)
+            else:
+                # ChebyKANLayer returns (B*P, d) like the reference's; restore (B, P, d) (SURVEY.md D3)
+                tokens = self.linear_mapper(patches).reshape(b, p, self.d_hidden)
+            cls = self.v_class.unsqueeze(0).expand(b, -1, -1)
+            out = torch.cat((cls, tokens), dim=1) + self.pos_embeddings[: p + 1]
         pending = None
         for blk in self.blocks:
             if isinstance(blk, TransformerBlock):
