@@ -2218,10 +2218,17 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     BasisGenP<FAM, JC> proto;          // knots / centres / frequencies / phases of this lane's feature, loaded once
     proto.prepare(b, f, j0);
 
-    const float* xcol = a.x + (long long)gx * a.I + f;
-    const float* ucol = RBF ? (a.u ? a.u + (long long)g0 * a.I + f : xcol) : xcol;
-    const long long ldu = RBF ? (a.u ? a.ldu : a.ldx) : a.ldx;
-    const float* dycol = a.dy + l31;
+    // Addressing: wave-uniform 64-bit bases (start of this slab) + 32-bit per-lane offsets, so that a load costs one or two
+    // VALU instructions for its address instead of a 64-bit multiply-add chain: the PMC pass of round 1 counted 3.5 VALU
+    // instructions per MFMA in this kernel, mostly address arithmetic, and the fp32 matrix pipe waits for every one of them
+    // (DESIGN.md section 4.1).  The host guarantees rows_per_split * max(ldx, ldu, ldy) < 2^29 elements.
+    const float* xbase = a.x + ms * a.ldx + (long long)gx * a.I;                                  // uniform
+    const float* ubase = RBF ? (a.u ? a.u + ms * a.ldu + (long long)g0 * a.I : xbase) : xbase;      // uniform
+    const int ldx32 = (int)a.ldx, ldu32 = RBF ? (a.u ? (int)a.ldu : (int)a.ldx) : (int)a.ldx, ldy32 = (int)a.ldy;
+    const float* dybase = a.dy + ms * a.ldy;                                                        // uniform
+    int dyo[NOT];
+#pragma unroll
+    for (int i = 0; i < NOT; ++i) dyo[i] = (int)tcol[i] + l31;
 
     f32x16 acc[JC][NOT];
 #pragma unroll
@@ -2239,11 +2246,11 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         for (int t = 0; t < NTOK; ++t) {
             int tk = tok_of(blk, t);
             if (tk > len - 1) tk = len - 1;
-            const long long m = ms + tk;
-            rx[q][t] = xcol[m * a.ldx];
-            if constexpr (RBF) ru[q][t] = ucol[m * ldu];
+            rx[q][t] = xbase[tk * ldx32 + f];
+            if constexpr (RBF) ru[q][t] = ubase[tk * ldu32 + f];
+            const int dyr = tk * ldy32;
 #pragma unroll
-            for (int i = 0; i < NOT; ++i) rdy[q][t][i] = dycol[m * a.ldy + tcol[i]];
+            for (int i = 0; i < NOT; ++i) rdy[q][t][i] = dybase[dyr + dyo[i]];
         }
     };
     const int tok_per_blk = BF ? 16 : 2 * UB;
@@ -3012,6 +3019,11 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     p.rows_per_slab = rps;
     p.slabs = (int)((d->M + rps - 1) / rps);
     if (units > (1LL << 30)) return p;
+    {       // 32-bit in-slab element offsets (see the kernel)
+        long long ld = d->ldx > d->ldy ? d->ldx : d->ldy;
+        if (d->ldu > ld) ld = d->ldu;
+        if (rps * ld + ld >= (1LL << 29)) return p;
+    }
     p.ws_bytes = p.slabs > 1 ? sizeof(float) * (size_t)p.slabs * d->groups * ((size_t)d->I * p.gp) * d->O : 0;
     p.ok = true;
     return p;

@@ -1,6 +1,7 @@
 """patchify + patch-embedding KAN layer + class token + position embedding in one kernel launch
 (kanvit_patch_embed_fwd).  The fused launch performs the same fp32 operations in the same order as the three-step path
-(gather is pure addressing; the epilogue adds bias, then pos), so outputs must be BITWISE equal to it, and it is checked
+(gather is pure addressing; the epilogue adds bias, then pos), so outputs must be BITWISE equal to it whenever both run
+the same kernel instantiation (patch width a multiple of the 8-feature chunk), and it is checked
 against the float64 oracle's VisionTransformer prologue (oracle.patchify / positional_embeddings, pinned to the reference
 by tests/test_oracle_golden.py) as well."""
 import pytest
@@ -41,10 +42,17 @@ def test_fused_patch_embedding_equals_three_step_path_and_oracle(t, geom):
         assert m._fused_embed is (True if fused else False)
         (out * wgt).sum().backward()
         res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
-    assert torch.equal(res[0][0], res[1][0])                       # same operations, same order
     assert set(res[0][1]) == set(res[1][1])
-    for k in res[0][1]:
-        assert torch.equal(res[0][1][k], res[1][1][k]), k          # the backward runs the same kernels on the same rows
+    if (chw[2] // npatch) % 8 == 0:
+        # both paths run the same kernel instantiation (8-feature chunks): same operations in the same order -> bitwise equal
+        assert torch.equal(res[0][0], res[1][0])
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k      # the backward runs the same kernels on the same rows
+    else:
+        # narrow patches: the gather needs a chunk that divides the patch width, i.e. another k order of the same fp32 sums
+        assert max_err(res[0][0], res[1][0]) < 2e-6 * max(1.0, float(res[1][0].abs().max()))
+        for k in res[0][1]:
+            assert rel_err(res[0][1][k], res[1][1][k]) < 1e-5, k
     # float64 oracle of the prologue (model.py:144-152)
     sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in m.state_dict().items()}
     patches = ko.patchify(x.cpu().double(), npatch)
