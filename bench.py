@@ -81,6 +81,7 @@ def host_cores():
 def cpu_baseline(model, wl, target_s=15.0):
     """Reference-faithful CPU train step (oracle/kan_oracle.py, the checker -- never the product)."""
     from oracle import kan_oracle as ko
+    ko.REFERENCE_OP_SEQUENCE = True          # the reference's own op sequences for ChebyKAN / SineKAN (calibrated: profiles/r02_cpu_baseline_calibration.json)
     torch.set_num_threads(host_cores())
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     n_patches, heads, t = wl["n_patches"], wl["heads"], wl["type"]

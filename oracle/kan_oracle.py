@@ -47,6 +47,10 @@ Tensor = torch.Tensor
 # no such mode (train.py has no AMP; SURVEY.md section 7 "bf16 parity"); with no rounding installed -- the default --
 # these functions are the plain restatement of the reference.
 _ROUND = None
+# bench.py's cpu_baseline leg sets this: ChebyKAN / SineKAN then run the reference's own (slower) op sequences, so that the
+# timed CPU port costs what the reference costs (tools/calibrate_cpu_baseline.py: within 10 % for every type).  Values are
+# identical either way (tests/test_oracle_golden.py runs both).
+REFERENCE_OP_SEQUENCE = False
 
 
 class operand_rounding:
@@ -141,6 +145,12 @@ def cheby_forward(x: Tensor, cheby_coeffs: Tensor, faithful: bool = True) -> Ten
     """
     in_dim, out_dim, deg1 = cheby_coeffs.shape
     t = torch.tanh(x).reshape(-1, in_dim)
+    if faithful and REFERENCE_OP_SEQUENCE and _ROUND is None:
+        # the reference's own op sequence (models/cheby.py:37-46), for the CPU-baseline timing: acos and cos run on the
+        # EXPANDED (M, I, D+1) tensor and the contraction is an einsum over (i, d) -- same values as below, ~1.5x the time
+        th = t.reshape(-1, in_dim, 1).expand(-1, -1, deg1).acos()
+        th = th * torch.arange(deg1, dtype=t.dtype)
+        return torch.einsum("bid,iod->bo", th.cos(), cheby_coeffs)
     if faithful:
         d = torch.arange(deg1, dtype=t.dtype)
         basis = torch.cos(torch.acos(t).unsqueeze(-1) * d)          # (M, I, D+1)
@@ -258,6 +268,14 @@ def sine_forward(x: Tensor, amplitudes: Tensor, freq: Tensor, phase: Tensor, bia
     out_f, in_f, g = amplitudes.shape
     lead = x.shape[:-1]
     x2 = x.reshape(-1, in_f)
+    if REFERENCE_OP_SEQUENCE and _ROUND is None:
+        # the reference's own op sequence (models/sinekan.py:84-89), for the CPU-baseline timing: a 4-D broadcast and an
+        # einsum over (input, grid) against amplitudes[O, I, G] -- same values as below
+        s4 = torch.sin(x2.reshape(x2.shape[0], 1, in_f, 1) * freq.reshape(1, 1, 1, g) + phase.reshape(1, 1, in_f, g))
+        y = torch.einsum("ijkl,jkl->ij", s4, amplitudes)
+        if bias is not None:
+            y = y + bias
+        return y.reshape(*lead, out_f)
     s = torch.sin(x2.reshape(-1, in_f, 1) * freq.reshape(1, 1, g) + phase.reshape(1, in_f, g))
     y = _mm(s.reshape(x2.shape[0], -1), amplitudes.reshape(out_f, -1).t())
     if bias is not None:

@@ -32,6 +32,21 @@ def test_layer_cases_fp32(fam):
             assert rel_err(gp[k], g) < 2e-4, (fam, c, k)
 
 
+@pytest.mark.parametrize("fam", ["cheby", "sine"])
+def test_reference_op_sequence_gives_the_same_values(fam, monkeypatch):
+    """bench.py's cpu_baseline leg times ChebyKAN / SineKAN in the reference's own op sequence (REFERENCE_OP_SEQUENCE): the
+    values must be the ones pinned above."""
+    monkeypatch.setattr(ko, "REFERENCE_OP_SEQUENCE", True)
+    blob = load_npz(f"layer_{fam}.npz")
+    for c in range(int(blob["n_cases"])):
+        p = f"c{c}."
+        y, gx, gp = _run(state_dict_from(blob, p), T(blob[p + "x"]))
+        assert max_err(y, T(blob[p + "y"])) < 2e-5, (fam, c)
+        assert rel_err(gx, T(blob[p + "grad_x"])) < 2e-4, (fam, c)
+        for k, g in grads_from(blob, p).items():
+            assert rel_err(gp[k], g) < 2e-4, (fam, c, k)
+
+
 @pytest.mark.parametrize("fam", FAMS)
 def test_layer_cases_fp64_truth(fam):
     """The float64 oracle is the 'truth' the GPU tests measure against; it must sit
