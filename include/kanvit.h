@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KANVIT_ABI_VERSION 4
+#define KANVIT_ABI_VERSION 5
 
 /* error codes */
 #define KANVIT_OK 0
@@ -45,6 +45,13 @@ extern "C" {
                                     at models/effkan.py:44-53 and never changes) -> closed-form cubic evaluation of
                                     the 4 non-zero bases instead of the Cox-de Boor recursion.  g0, h are read from
                                     the first two knots of each group.                                              */
+#define KANVIT_FLAG_FUSED_LN 8   /* RBF (FastKAN): the LayerNorm in front of the spline path (models/fastkan.py:68) is formed IN the
+                                    kernels: u = (x - mean) * rstd * gamma + beta over the I features of the group's x slice,
+                                    eps = ln_eps.  bparams of a group = [centres(G) | gamma(I) | beta(I)].  The `u` argument
+                                    of the three entry points then carries a statistics buffer float[M][x_group_mod][2]
+                                    (mean, rstd per row and x slice): WRITTEN by kanvit_layer_fwd, read by the backward
+                                    calls; `du` still receives d loss / d u (the caller applies the LayerNorm backward).
+                                    Only shapes for which kanvit_layer_ln_fusable() returns 1.                          */
 #define KANVIT_FLAG_SHARED_BPARAMS 4 /* groups that read the same x columns (q, k, v of a head) also have identical
                                     basis parameters, so one basis tile may serve all of them (as for the
                                     parameter-free families).  Honoured for BSPLINE.                                */
@@ -92,12 +99,25 @@ typedef struct kanvit_layer_desc {
     int64_t ldu;           /* row stride of u and du (RBF; group g uses columns [g*I, +I))  */
     int64_t ldy;           /* row stride of y and dy (group g uses columns [g*O, +O))       */
     int64_t bparam_stride; /* floats between consecutive groups in bparams                  */
+    float ln_eps;          /* KANVIT_FLAG_FUSED_LN: epsilon of the fused LayerNorm          */
+    int32_t reserved;
 } kanvit_layer_desc;
+
+/* 1 if KANVIT_FLAG_FUSED_LN may be set for this layer (register kernels cover forward and both gradients), else 0 */
+int kanvit_layer_ln_fusable(const kanvit_layer_desc* d);
+
+/* Backward of the fused LayerNorm (what autograd does for models/fastkan.py:68's nn.LayerNorm), given du from
+ * kanvit_layer_bwd_input and the statistics kanvit_layer_fwd wrote:  dx[M][ldx] += LN-backward (IN PLACE, may be NULL),
+ * dgamma / dbeta [groups][I] = column sums.  Deterministic (fixed-order partial sums in the workspace).              */
+size_t kanvit_layer_ln_bwd_workspace(const kanvit_layer_desc* d);
+int kanvit_layer_ln_bwd(const kanvit_layer_desc* d, const float* x, const float* stats, const float* bparams, const float* du,
+                        float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused basis evaluation + coefficient contraction -------------------------------------
  * forward of models/cheby.py:36-48, models/effkan.py:174-187, models/fastkan.py:66-76 (the
  * LayerNorm of :68 is applied by the caller and passed as u; u = NULL means u = x),
- * models/nfkan.py:36-52, models/sinekan.py:81-91, and nn.Linear (attention.py:136-142).      */
+ * models/nfkan.py:36-52, models/sinekan.py:81-91, and nn.Linear (attention.py:136-142).
+ * With KANVIT_FLAG_FUSED_LN the LayerNorm is applied inside the kernel and `u` is the statistics buffer (see the flag). */
 size_t kanvit_layer_fwd_workspace(const kanvit_layer_desc* d);   /* 0 unless KANVIT_FLAG_BF16_MFMA (repacked weights) */
 int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u, const float* w,
                      const float* bparams, const float* bias, float* y, void* workspace, size_t workspace_bytes,

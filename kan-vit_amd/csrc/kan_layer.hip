@@ -62,6 +62,12 @@ struct LayerArgs {
     int pg, pg_C, pg_H, pg_W, pg_n, pg_pre;
     const float* cls;
     const float* pos;
+    // KANVIT_FLAG_FUSED_LN (RBF): the spline-path input u = LayerNorm(x slice) * gamma + beta (models/fastkan.py:68) is formed
+    // in the kernels; bparams of a group = [centres(G) | gamma(I) | beta(I)]; stats[M][xmod][2] = (mean, rstd) per row and x
+    // slice, written by the forward kernel and read by the two backward kernels
+    int ln;
+    float ln_eps;
+    float* stats;
 };
 
 __device__ __forceinline__ BasisArgs make_basis(const LayerArgs& a, int g) {
@@ -75,6 +81,28 @@ __device__ __forceinline__ BasisArgs make_basis(const LayerArgs& a, int g) {
     b.bp = a.bp ? a.bp + (long long)g * a.bp_stride : nullptr;
     b.uniform = (a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3;
     return b;
+}
+
+// LayerNorm statistics of one row of I features held by a lane pair: this lane sees ICH consecutive features of every
+// chunk of 2*ICH (xh points at its first one), its partner lane (l ^ 32) the others.  Two passes (mean, then centred
+// sum of squares: the accuracy of torch's Welford kernel), biased variance, rstd = rsqrt(var + eps) as nn.LayerNorm.
+template <int ICH>
+__device__ __forceinline__ void kv_ln_row_stats(const float* __restrict__ xh, int nch, int I, float eps, float& mean, float& rstd) {
+    float s = 0.0f;
+    for (int c = 0; c < nch; ++c)
+#pragma unroll
+        for (int e = 0; e < ICH; ++e) s += xh[c * 2 * ICH + e];
+    s += __shfl_xor(s, 32);
+    mean = s / (float)I;
+    float q = 0.0f;
+    for (int c = 0; c < nch; ++c)
+#pragma unroll
+        for (int e = 0; e < ICH; ++e) {
+            const float d = xh[c * 2 * ICH + e] - mean;
+            q = fmaf(d, d, q);
+        }
+    q += __shfl_xor(q, 32);
+    rstd = rsqrtf(q / (float)I + eps);
 }
 
 __device__ __forceinline__ int kv_pow2_ge(int v) {
@@ -423,6 +451,18 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
     long long yrow = m0 + row;                    // output row of this lane's input row
     const float* posrow = nullptr;                // position embedding row added to it
     bool cls_owner = false;                       // this lane also writes its sample's class-token row
+    float ln_mean = 0.0f, ln_rstd = 1.0f;        // KANVIT_FLAG_FUSED_LN: statistics of this lane's row over the group's x slice
+    const float* ln_gb = nullptr;                 // gamma of this lane's first feature (beta I floats further on)
+    if constexpr (RBF) {
+        if (a.ln) {
+            kv_ln_row_stats<ICH>(xrow, nch, a.I, a.ln_eps, ln_mean, ln_rstd);
+            ln_gb = b.bp + a.G + hf * ICH;
+            if (hf == 0 && row_ok && gs < a.xmod) {
+                float2 st = {ln_mean, ln_rstd};
+                *reinterpret_cast<float2*>(a.stats + ((m0 + row) * a.xmod + gs) * 2) = st;
+            }
+        }
+    }
     int pg_ix = 0, pg_iy = 0, pg_off = 0, pg_pw = 0, pg_ph = 0;
     if (a.pg) {
         const int P = a.pg_n * a.pg_n;
@@ -484,7 +524,7 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
             const f32x4 v = *reinterpret_cast<const f32x4*>(xs);
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = v[e];
-            if (RBF) {
+            if (RBF && !a.ln) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(urow + c * IC);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) uv[e] = w4[e];
@@ -493,7 +533,13 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
 #pragma unroll
             for (int e = 0; e < ICH; ++e) {
                 xv[e] = xs[e];
-                if (RBF) uv[e] = urow[c * IC + e];
+                if (RBF && !a.ln) uv[e] = urow[c * IC + e];
+            }
+        }
+        if constexpr (RBF) {
+            if (a.ln) {                           // u = (x - mean) * rstd * gamma + beta, the operation order of nn.LayerNorm
+#pragma unroll
+                for (int e = 0; e < ICH; ++e) uv[e] = (xv[e] - ln_mean) * ln_rstd * ln_gb[c * IC + e] + ln_gb[a.I + c * IC + e];
             }
         }
         if (a.pg) {                               // next chunk: IC pixels further along the line, then next line, then next channel
@@ -760,9 +806,16 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
             float duv[RBF ? FPH : 1];
             float uvv[RBF ? FPH : 1];
             if constexpr (RBF) {
-                const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
+                if (a.ln) {                       // KANVIT_FLAG_FUSED_LN: u from x, the saved row statistics and this group's gamma / beta
+                    const float2 st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
+                    const float* gb = b.bp + a.G + ci * IC + hf * FPH;
 #pragma unroll
-                for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
+                    for (int j = 0; j < FPH; ++j) uvv[j] = (xv[j] - st.x) * st.y * gb[j] + gb[a.I + j];
+                } else {
+                    const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
+                }
             }
             float dfq[SINE ? GP : 1];
             if constexpr (SINE) {
@@ -1139,6 +1192,18 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
     const bool row_ok = row < mrem;
     const float* xrow = a.x + (m0 + (row_ok ? row : 0)) * a.ldx + xcol + hf * ICH;
     const float* urow = (RBF && a.u) ? a.u + (m0 + (row_ok ? row : 0)) * a.ldu + (long long)gs * a.I + hf * ICH : xrow;
+    float ln_mean = 0.0f, ln_rstd = 1.0f;        // KANVIT_FLAG_FUSED_LN (see kan_fwd_reg_kernel)
+    const float* ln_gb = nullptr;
+    if constexpr (RBF) {
+        if (a.ln) {
+            kv_ln_row_stats<ICH>(xrow, nch, a.I, a.ln_eps, ln_mean, ln_rstd);
+            ln_gb = b.bp + a.G + hf * ICH;
+            if (hf == 0 && row_ok && gs < a.xmod) {
+                float2 st = {ln_mean, ln_rstd};
+                *reinterpret_cast<float2*>(a.stats + ((m0 + row) * a.xmod + gs) * 2) = st;
+            }
+        }
+    }
 
     u32x4 wreg[NSH][WQ];
     auto load_w = [&](int c) {
@@ -1180,7 +1245,7 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
                 const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + c * IC + 4 * j4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xv[4 * j4 + e] = v[e];
-                if (RBF) {
+                if (RBF && !a.ln) {
                     const f32x4 w4 = *reinterpret_cast<const f32x4*>(urow + c * IC + 4 * j4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) uv[4 * j4 + e] = w4[e];
@@ -1190,7 +1255,13 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
 #pragma unroll
             for (int e = 0; e < ICH; ++e) {
                 xv[e] = xrow[c * IC + e];
-                if (RBF) uv[e] = urow[c * IC + e];
+                if (RBF && !a.ln) uv[e] = urow[c * IC + e];
+            }
+        }
+        if constexpr (RBF) {
+            if (a.ln) {
+#pragma unroll
+                for (int e = 0; e < ICH; ++e) uv[e] = (xv[e] - ln_mean) * ln_rstd * ln_gb[c * IC + e] + ln_gb[a.I + c * IC + e];
             }
         }
     };
@@ -1582,9 +1653,16 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const La
             float duv[RBF ? FPH : 1];
             float uvv[RBF ? FPH : 1];
             if constexpr (RBF) {
-                const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
+                if (a.ln) {                       // KANVIT_FLAG_FUSED_LN: u from x, the saved row statistics and this group's gamma / beta
+                    const float2 st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
+                    const float* gb = b.bp + a.G + ci * IC + hf * FPH;
 #pragma unroll
-                for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
+                    for (int j = 0; j < FPH; ++j) uvv[j] = (xv[j] - st.x) * st.y * gb[j] + gb[a.I + j];
+                } else {
+                    const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
+                }
             }
 #pragma unroll
             for (int j = 0; j < FPH; ++j) {
@@ -2240,6 +2318,23 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
 
     // token of (block, step u, e): fp32: 2*(blk*UB + u) + hf ; bf16: 16*blk + 8*hf + e
     float rx[PD][NTOK], ru[RBF ? PD : 1][RBF ? NTOK : 1], rdy[PD][NTOK][NOT];
+    // KANVIT_FLAG_FUSED_LN: u = (x - mean) * rstd * gamma + beta is formed when a block leaves the ring.  The slab's (mean, rstd)
+    // pairs sit in a wave-private LDS strip (the register file is full: a second ring for them spills), filled once up front
+    // and read back as two-address broadcasts; no barrier -- the strip belongs to this wave alone.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool ln = RBF && a.ln;
+    float ln_g = 1.0f, ln_b = 0.0f;               // gamma / beta of this lane's feature
+    const float2* st_w = nullptr;
+    if constexpr (RBF) {
+        if (ln) {
+            ln_g = b.bp[a.G + f];
+            ln_b = b.bp[a.G + a.I + f];
+            float2* strip = reinterpret_cast<float2*>(smem) + (size_t)wave * a.rows_per_split;
+            const float* stbase = a.stats + (ms * a.xmod + gx) * 2;      // uniform
+            for (int i = lane; i < len; i += 64) strip[i] = *reinterpret_cast<const float2*>(stbase + (size_t)i * (2 * a.xmod));
+            st_w = strip;
+        }
+    }
     auto tok_of = [&](int blk, int t) -> int { return BF ? (16 * blk + 8 * hf + t) : (2 * (blk * UB + t) + hf); };
     auto load_block = [&](int q, int blk) {
 #pragma unroll
@@ -2247,7 +2342,9 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
             int tk = tok_of(blk, t);
             if (tk > len - 1) tk = len - 1;
             rx[q][t] = xbase[tk * ldx32 + f];
-            if constexpr (RBF) ru[q][t] = ubase[tk * ldu32 + f];
+            if constexpr (RBF) {
+                if (!ln) ru[q][t] = ubase[tk * ldu32 + f];
+            }
             const int dyr = tk * ldy32;
 #pragma unroll
             for (int i = 0; i < NOT; ++i) rdy[q][t][i] = dybase[dyr + dyo[i]];
@@ -2270,7 +2367,15 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                 for (int t = 0; t < NTOK; ++t) {
                     const bool ok = tok_of(blk, t) < len;
                     cx[t] = rx[q][t];
-                    if constexpr (RBF) cu[t] = ru[q][t];
+                    if constexpr (RBF) {
+                        if (ln) {
+                            const int tk = tok_of(blk, t);
+                            const float2 st = st_w[tk < len ? tk : len - 1];
+                            cu[t] = (rx[q][t] - st.x) * st.y * ln_g + ln_b;
+                        } else {
+                            cu[t] = ru[q][t];
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < NOT; ++i) cdy[t][i] = ok ? rdy[q][t][i] : 0.0f;
                 }
@@ -2370,6 +2475,10 @@ int gp_of(const kanvit_layer_desc* d) {
     }
 }
 
+}  // namespace
+extern "C" int kanvit_layer_ln_fusable(const kanvit_layer_desc* d);
+namespace {
+
 int validate(const kanvit_layer_desc* d, const char* who) {
     if (!d) return kv_fail(KANVIT_EINVAL, "%s: null descriptor", who);
     const int gp = gp_of(d);
@@ -2396,6 +2505,12 @@ int validate(const kanvit_layer_desc* d, const char* who) {
         if (d->bparam_stride < (int64_t)d->I * nk) return kv_fail(KANVIT_EINVAL, "%s: bparam_stride too small", who);
     }
     if (d->family == KANVIT_RBF && d->bparam_stride < d->G) return kv_fail(KANVIT_EINVAL, "%s: bparam_stride too small", who);
+    if (d->flags & KANVIT_FLAG_FUSED_LN) {
+        if (d->family != KANVIT_RBF) return kv_fail(KANVIT_EINVAL, "%s: KANVIT_FLAG_FUSED_LN is an RBF (FastKAN) flag", who);
+        if (d->bparam_stride < (int64_t)d->G + 2 * (int64_t)d->I)
+            return kv_fail(KANVIT_EINVAL, "%s: KANVIT_FLAG_FUSED_LN needs bparams = [centres(G) | gamma(I) | beta(I)] per group", who);
+        if (!kanvit_layer_ln_fusable(d)) return kv_fail(KANVIT_EINVAL, "%s: shape not covered by the register kernels that fuse the LayerNorm", who);
+    }
     if (d->family == KANVIT_SINE && d->bparam_stride < (int64_t)d->G * (1 + d->I))
         return kv_fail(KANVIT_EINVAL, "%s: bparam_stride too small", who);
     return 0;
@@ -2420,6 +2535,8 @@ LayerArgs base_args(const kanvit_layer_desc* d) {
     a.K = d->I * a.GP;
     a.rbf_inv_h = d->rbf_inv_h;
     a.flags = d->flags;
+    a.ln = (d->family == KANVIT_RBF && (d->flags & KANVIT_FLAG_FUSED_LN)) ? 1 : 0;
+    a.ln_eps = d->ln_eps;
     return a;
 }
 
@@ -2691,6 +2808,7 @@ int dispatch_fwd(LayerArgs& a, hipStream_t st) {
     {
         const int rc = try_fwd_reg<FAM>(a, st);      // register-operand kernel when the shape allows it
         if (rc <= 0) return rc;
+        if (a.ln) return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: KANVIT_FLAG_FUSED_LN needs the register kernel (alignment / shape)");
     }
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     const int nshare = a.groups / a.xmod;
@@ -2889,6 +3007,7 @@ int dispatch_bwd_input(LayerArgs& a, hipStream_t st) {
     if (!bf) {
         const int rc = try_bwd_input_reg<FAM>(a, st);   // register-form kernel when the shape allows it
         if (rc <= 0) return rc;
+        if (a.ln) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: KANVIT_FLAG_FUSED_LN needs the register kernel (alignment / shape)");
     }
     int ic = bwd_input_ic<FAM>(a.I, a.GP, a.G, nshare, bf ? a.O : 0);
     if (!ic && bf) {
@@ -3014,8 +3133,12 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     if (S > smax) S = smax;
     if (S < 1) S = 1;
     if (S > 65535) S = 65535;
+    const bool ln = fam == KANVIT_RBF && (d->flags & KANVIT_FLAG_FUSED_LN);
+    if (ln && S * 4096 < d->M) S = (d->M + 4095) / 4096;      // fused LayerNorm: a wave's (mean, rstd) strip is 8 bytes per slab row of LDS
+    if (S > 65535) return p;
     long long rps = (d->M + S - 1) / S;
     rps = (rps + 15) / 16 * 16;
+    if (ln && rps > 4096) return p;
     p.rows_per_slab = rps;
     p.slabs = (int)((d->M + rps - 1) / rps);
     if (units > (1LL << 30)) return p;
@@ -3033,10 +3156,15 @@ template <int FAM, int GP, int NOT, int JC = GP>
 int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
     const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
     dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
+    const size_t lds = a.ln ? (size_t)4 * p.rows_per_slab * sizeof(float2) : 0;      // four wave-private (mean, rstd) strips
+    if (lds > 64 * 1024) {
+        if (bf) KV_ALLOW_LDS(160 * 1024, (kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>));
+        else KV_ALLOW_LDS(160 * 1024, (kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>));
+    }
     if (bf)
-        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>), grid, dim3(256), lds, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     else
-        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>), grid, dim3(256), lds, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
     return 0;
 }
@@ -3084,6 +3212,7 @@ static void kv_config_load() {
     c.no_pipe = flag("KANVIT_NO_PIPE");
     c.no_ws = flag("KANVIT_NO_WS");
     c.no_bf16 = flag("KANVIT_NO_BF16");
+    c.no_fused_ln = flag("KANVIT_NO_FUSED_LN");
     c.attn_v1 = flag("KANVIT_ATTN_V1");
     c.attn_v2 = flag("KANVIT_ATTN_V2");
     c.attn_no_ds = flag("KANVIT_ATTN_NO_DS");
@@ -3091,8 +3220,8 @@ static void kv_config_load() {
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d",
-             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic);
+             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d",
+             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }
@@ -3142,6 +3271,11 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
     a.bp = bparams;
     a.bias = bias;
     a.y = y;
+    if (a.ln) {                       // the u slot carries the statistics buffer [M][x_group_mod][2] (written here)
+        if (!u || ((uintptr_t)u & 7)) return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: KANVIT_FLAG_FUSED_LN needs the (8-byte aligned) statistics buffer in the u argument");
+        a.stats = const_cast<float*>(u);
+        a.u = nullptr;
+    }
     hipStream_t st = (hipStream_t)stream;
     if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16) {
         const FwdRegBf16Plan pr = plan_fwd_reg_bf16(d);
@@ -3154,7 +3288,7 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
 #undef KV_CALL
         }
         const FwdBf16Plan p = plan_fwd_bf16(d);
-        if (p.ok) {
+        if (p.ok && !a.ln) {
             if (!workspace || workspace_bytes < p.ws_bytes || ((uintptr_t)workspace & 15))
                 return kv_fail(KANVIT_ENOMEM, "kanvit_layer_fwd: workspace %zu bytes < required %zu (or not 16-byte aligned)",
                                workspace_bytes, p.ws_bytes);
@@ -3166,6 +3300,23 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
 #define KV_CALL(F) dispatch_fwd<F>(a, st)
     KV_FAMILY_SWITCH(d->family, KV_CALL)
 #undef KV_CALL
+}
+
+/* 1 when the three register kernels that can form the FastKAN LayerNorm in-kernel cover this layer (pure host function) */
+int kanvit_layer_ln_fusable(const kanvit_layer_desc* d) {
+    if (!d || d->family != KANVIT_RBF || !d->has_base || d->G != 8 || d->groups < 1 || d->x_group_mod < 1) return 0;
+    if (d->I % 32 || d->O % 32 || d->M < 256 || (d->ldx & 3) || (d->ldy & 3)) return 0;
+    if (d->O > 64 && d->O % 128) return 0;                 // forward column tiling: 32, 64 or multiples of 128
+    {                                                      // kanvit_layer_ln_bwd's lane-group layout
+        const int ns = d->groups / d->x_group_mod;
+        if (d->groups % d->x_group_mod || (ns != 1 && ns != 3) || d->I > (ns == 3 ? 512 : 1024)) return 0;
+    }
+    if (kv_config().no_reg || kv_config().no_reg_bw || kv_config().no_fused_ln) return 0;
+    kanvit_layer_desc e = *d;
+    e.flags |= KANVIT_FLAG_FUSED_LN;
+    if (!plan_bwd_weight_reg(&e).ok) return 0;
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16 && !plan_fwd_reg_bf16(&e).ok) return 0;
+    return 1;
 }
 
 // ---- fused patch embedding (model.py:111-126 patchify, :144-152 class token + position embedding) ----
@@ -3279,6 +3430,11 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
     a.du = du;
     a.dparam = dparam;
     a.wb2 = nullptr;
+    if (a.ln) {
+        if (!u) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: KANVIT_FLAG_FUSED_LN needs the statistics buffer in the u argument");
+        a.stats = const_cast<float*>(u);
+        a.u = nullptr;
+    }
     if (bwd_input_bf16_ok(d) && (((uintptr_t)dy & 15) == 0)) {
         const size_t need = kanvit_layer_bwd_input_workspace(d);
         if (need) {
@@ -3296,6 +3452,7 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
             KV_FAMILY_SWITCH(d->family, KV_CALL)
 #undef KV_CALL
         }
+        if (a.ln) a.wb2 = nullptr;     // no LayerNorm fusion in the LDS-tile bf16 kernel: the exact register kernel runs instead
     }
 #define KV_CALL(F) dispatch_bwd_input<F>(a, st)
     KV_FAMILY_SWITCH(d->family, KV_CALL)
@@ -3332,8 +3489,14 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
     a.u = u;
     a.bp = bparams;
     a.dy = dy;
+    if (a.ln) {
+        if (!u) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: KANVIT_FLAG_FUSED_LN needs the statistics buffer in the u argument");
+        a.stats = const_cast<float*>(u);
+        a.u = nullptr;
+    }
     {
         const BwRegPlan pr = plan_bwd_weight_reg(d);
+        if (!pr.ok && a.ln) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: KANVIT_FLAG_FUSED_LN needs the register kernel (shape)");
         if (pr.ok) {
             hipStream_t st = (hipStream_t)stream;
             const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;

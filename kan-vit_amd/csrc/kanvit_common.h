@@ -45,13 +45,14 @@ struct KvConfig {
     int no_pipe;         // KANVIT_NO_PIPE         fp32 register kernels without the one-step-ahead LDS fragment prefetch (round-1 form)
     int no_ws;           // KANVIT_NO_WS           W-stationary bf16 forward off
     int no_bf16;         // KANVIT_NO_BF16         ignore KANVIT_FLAG_BF16_MFMA (exact fp32 kernels)
+    int no_fused_ln;     // KANVIT_NO_FUSED_LN     kanvit_layer_ln_fusable() answers 0: FastKAN's LayerNorm stays a separate op
     int attn_v1;         // KANVIT_ATTN_V1         first-form attention kernels
     int attn_v2;         // KANVIT_ATTN_V2         second-form fp32 attention kernels (round 1) instead of the pipelined third form
     int attn_no_ds;      // KANVIT_ATTN_NO_DS      fp32 attention backward without the dS hand-off
     int attn_grid;       // KANVIT_ATTN_GRID       work-groups of the persistent attention kernels (tuning; 0 = one round of resident ones)
     int bf16_nsh;        // KANVIT_BF16_NSH        LDS-tile bf16 forward: groups per basis tile (tuning)
     int bf16_ic;         // KANVIT_BF16_IC         LDS-tile bf16 forward: feature chunk cap (tuning)
-    char text[320];
+    char text[352];
 };
 const KvConfig& kv_config();
 

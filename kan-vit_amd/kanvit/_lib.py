@@ -19,6 +19,7 @@ LINEAR, CHEBY, BSPLINE, RBF, SINE, FOURIER = range(6)
 FLAG_BF16_MFMA = 1
 FLAG_UNIFORM_KNOTS = 2
 FLAG_SHARED_BPARAMS = 4
+FLAG_FUSED_LN = 8
 FAMILY_NAMES = ["linear", "cheby", "bspline", "rbf", "sine", "fourier"]
 
 
@@ -30,7 +31,7 @@ class LayerDesc(C.Structure):
     _fields_ = [("family", C.c_int32), ("groups", C.c_int32), ("x_group_mod", C.c_int32), ("I", C.c_int32),
                 ("O", C.c_int32), ("G", C.c_int32), ("spline_order", C.c_int32), ("has_base", C.c_int32),
                 ("rbf_inv_h", C.c_float), ("flags", C.c_int32), ("M", C.c_int64), ("ldx", C.c_int64),
-                ("ldu", C.c_int64), ("ldy", C.c_int64), ("bparam_stride", C.c_int64)]
+                ("ldu", C.c_int64), ("ldy", C.c_int64), ("bparam_stride", C.c_int64), ("ln_eps", C.c_float), ("reserved", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -59,6 +60,9 @@ SYMBOLS = {
     "kanvit_device_count": (C.c_int, []),
     "kanvit_config": (C.c_char_p, []),
     "kanvit_config_reload": (C.c_int, []),
+    "kanvit_layer_ln_fusable": (C.c_int, [C.POINTER(LayerDesc)]),
+    "kanvit_layer_ln_bwd_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
+    "kanvit_layer_ln_bwd": (C.c_int, [C.POINTER(LayerDesc)] + [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p]),
     "kanvit_layer_fwd_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_bwd_input_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_fwd": (C.c_int, _LAYER_FWD),
@@ -99,7 +103,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.kanvit_abi_version() != 4:
+        if handle.kanvit_abi_version() != 5:
             raise KanvitError("libkanvit.so ABI version mismatch")
         _lib = handle
     return _lib

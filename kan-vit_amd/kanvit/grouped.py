@@ -60,6 +60,10 @@ def _cfg_pack(m):
 def run_single(layer, x2d: torch.Tensor) -> torch.Tensor:
     """y[M, O] for one layer on a 2-D input."""
     cfg, (w, bp, bias) = _cfg_pack(layer)
+    if hasattr(layer, "kan_ln") and layer.kan_ln() is not None and ops.ln_fusable(cfg, x2d.shape[0]):
+        ln = layer.kan_ln()           # FastKAN: the LayerNorm of the spline path is formed inside the kernels
+        return ops.kan_layer_ln(x2d, w.unsqueeze(0), cfg, torch.cat([bp, ln.weight, ln.bias]).unsqueeze(0),
+                                None if bias is None else bias.reshape(1, -1), ln.eps)
     u = layer.kan_u(x2d) if hasattr(layer, "kan_u") else None
     return ops.kan_layer(x2d, w.unsqueeze(0), cfg, u=u,
                          bparams=None if bp is None else bp.unsqueeze(0),
@@ -88,6 +92,10 @@ def run_qkv(q_layers: Sequence, k_layers: Sequence, v_layers: Sequence, x2d: tor
         bias = None if layers[0].bias is None else stack_params([m.bias for m in layers])
     else:
         w, bp, bias = type(layers[0]).kan_pack_grouped(layers)
+    if hasattr(layers[0], "kan_ln") and layers[0].kan_ln() is not None and ops.ln_fusable(cfg, x2d.shape[0]):
+        gamma = stack_params([l.kan_ln().weight for l in layers])
+        beta = stack_params([l.kan_ln().bias for l in layers])
+        return ops.kan_layer_ln(x2d, w, cfg, torch.cat([bp, gamma, beta], dim=1), bias, layers[0].kan_ln().eps)
     u = None
     if hasattr(layers[0], "kan_u_grouped"):
         u = type(layers[0]).kan_u_grouped(layers, x2d, H)

@@ -29,6 +29,7 @@ class LayerCfg:
     has_base: int = 0
     rbf_inv_h: float = 0.0
     flags: int = 0          # _lib.FLAG_BF16_MFMA: contract on the bf16 matrix cores (set under bf16 autocast)
+    ln_eps: float = 0.0     # _lib.FLAG_FUSED_LN (FastKAN): epsilon of the LayerNorm formed inside the kernels
 
     @property
     def GP(self) -> int:
@@ -109,7 +110,7 @@ def _require_gpu_f32(name: str, t: Optional[torch.Tensor]):
 
 def _desc(cfg: LayerCfg, M: int, ldx: int, ldu: int, ldy: int, bp_stride: int) -> LayerDesc:
     return LayerDesc(cfg.family, cfg.groups, cfg.x_group_mod, cfg.I, cfg.O, cfg.G, cfg.spline_order, cfg.has_base,
-                     cfg.rbf_inv_h, cfg.flags, M, ldx, ldu, ldy, bp_stride)
+                     cfg.rbf_inv_h, cfg.flags, M, ldx, ldu, ldy, bp_stride, cfg.ln_eps, 0)
 
 
 def _workspace(nbytes: int, device):
@@ -210,6 +211,90 @@ def _kan_backward(cfg: "LayerCfg", x, u, w, bparams, dy, needs, has_u, has_bias)
         if need_b and has_bias:
             db = dy.view(M, cfg.groups, cfg.O).sum(0)
     return (dx if need_x else None), (du if need_u else None), dw, dbp, db
+
+
+def ln_fusable(cfg: "LayerCfg", M: int) -> bool:
+    """True when the register kernels can form FastKAN's LayerNorm themselves for this launch (kanvit_layer_ln_fusable)."""
+    if cfg.family != RBF:
+        return False
+    f = cfg.flags | (_lib.FLAG_BF16_MFMA if _autocast_flags() else 0)
+    d = _desc(LayerCfg(**{**cfg.__dict__, "flags": f}), M, cfg.x_group_mod * cfg.I, cfg.groups * cfg.I, cfg.groups * cfg.O,
+              cfg.G + 2 * cfg.I)
+    return bool(_lib.lib().kanvit_layer_ln_fusable(C.byref(d)))
+
+
+class _KanLayerLnFn(torch.autograd.Function):
+    """FastKAN launch with the LayerNorm of the spline path formed IN the kernels (KANVIT_FLAG_FUSED_LN):
+    y = spline(rbf(LN_g(x_slice))) + base(silu(x_slice)) for every group g, bparams[g] = [centres | gamma_g | beta_g].
+
+    The forward kernel computes each row slice's (mean, rstd), normalises on the fly and writes the statistics [M, x_group_mod, 2];
+    the [M, groups*I] normalised tensor u is never materialised (one write + three reads of it per step saved).  Backward: both
+    gradient kernels rebuild u from x and the saved statistics; the input-gradient kernel still returns d loss / d u, from which
+    the LayerNorm backward (d gamma, d beta, d x) is the standard closed form over the saved statistics (models/fastkan.py:68's
+    nn.LayerNorm, biased variance)."""
+
+    @staticmethod
+    @_fwd_f32
+    def forward(ctx, x, w, bparams, bias, cfg: LayerCfg):
+        for n, t in (("x", x), ("w", w), ("bparams", bparams), ("bias", bias)):
+            _require_gpu_f32(n, t)
+        x, w, bparams = x.contiguous(), w.contiguous(), bparams.contiguous()
+        bias = None if bias is None else bias.contiguous()
+        M, ldx = x.shape
+        if ldx != cfg.x_group_mod * cfg.I:
+            raise KanvitError(f"x has {ldx} columns, expected x_group_mod*I = {cfg.x_group_mod * cfg.I}")
+        if tuple(w.shape) != (cfg.groups, cfg.K, cfg.O):
+            raise KanvitError(f"packed weight shape {tuple(w.shape)} != {(cfg.groups, cfg.K, cfg.O)}")
+        if tuple(bparams.shape) != (cfg.groups, cfg.G + 2 * cfg.I):
+            raise KanvitError(f"bparams shape {tuple(bparams.shape)} != {(cfg.groups, cfg.G + 2 * cfg.I)} (centres | gamma | beta)")
+        y = torch.empty(M, cfg.groups * cfg.O, device=x.device, dtype=torch.float32)
+        stats = torch.empty(M, cfg.x_group_mod, 2, device=x.device, dtype=torch.float32)
+        d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, bparams.shape[1])
+        tag = ("qkv" if cfg.groups > 1 else "layer") + "_fwd" + ("_bf16" if cfg.flags & _lib.FLAG_BF16_MFMA else "")
+        with torch.cuda.device(x.device):
+            nbytes = int(_lib.lib().kanvit_layer_fwd_workspace(C.byref(d)))
+            ws = _workspace(nbytes, x.device) if nbytes else None
+            with _timed(tag, *_layer_cost(cfg, M, "fwd")):
+                check(_lib.lib().kanvit_layer_fwd(C.byref(d), _ptr(x), _ptr(stats), _ptr(w), _ptr(bparams), _ptr(bias),
+                                                  _ptr(y), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_fwd")
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, stats, w, bparams)
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dy):
+        x, stats, w, bparams = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_x, need_w, need_bp, need_b = ctx.needs_input_grad[:4]
+        need_ln = need_x or need_bp
+        dx, du, dw, _, db = _kan_backward(cfg, x, stats, w, bparams, dy.float().contiguous(),
+                                          (need_ln, need_ln, need_w, False, need_b), True, ctx.has_bias)
+        dbp = None
+        if need_ln:
+            # LayerNorm backward from du and the saved statistics: dx += ..., d gamma, d beta in one pass (kanvit_layer_ln_bwd)
+            M, I, G = x.shape[0], cfg.I, cfg.G
+            d = _desc(cfg, M, x.shape[1], cfg.groups * I, cfg.groups * cfg.O, bparams.shape[1])
+            L = _lib.lib()
+            dgb = torch.empty(2, cfg.groups, I, device=x.device, dtype=torch.float32)
+            with torch.cuda.device(x.device):
+                nbytes = int(L.kanvit_layer_ln_bwd_workspace(C.byref(d)))
+                ws = _workspace(nbytes, x.device)
+                with _timed("ln_bwd", 0, 4 * M * (cfg.groups * I + (3 if need_x else 1) * cfg.x_group_mod * I)):
+                    check(L.kanvit_layer_ln_bwd(C.byref(d), _ptr(x), _ptr(stats), _ptr(bparams), _ptr(du), _ptr(dx if need_x else None),
+                                                _ptr(dgb[0]), _ptr(dgb[1]), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_ln_bwd")
+            if need_bp:
+                dbp = torch.cat([torch.zeros(cfg.groups, G, device=x.device, dtype=torch.float32), dgb[0], dgb[1]], dim=1)
+        return (dx if need_x else None), dw, dbp, db, None
+
+
+def kan_layer_ln(x: torch.Tensor, w: torch.Tensor, cfg: LayerCfg, bparams: torch.Tensor, bias: Optional[torch.Tensor],
+                 eps: float) -> torch.Tensor:
+    """kan_layer() for FastKAN with the LayerNorm fused (call only when ln_fusable(cfg, M)); bparams = [centres | gamma | beta]."""
+    from dataclasses import replace
+    f = cfg.flags | _lib.FLAG_FUSED_LN | (_lib.FLAG_BF16_MFMA if _autocast_flags() else 0)
+    return _KanLayerLnFn.apply(x, w, bparams, bias, replace(cfg, flags=f, ln_eps=float(eps)))
 
 
 def patchify(images: torch.Tensor, n_patches: int) -> torch.Tensor:

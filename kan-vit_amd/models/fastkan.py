@@ -87,6 +87,10 @@ class FastKANLayer(nn.Module):
     def kan_u(self, x2d):
         return self.layernorm(x2d) if getattr(self, "_use_ln", True) else None
 
+    def kan_ln(self):
+        """The LayerNorm to fuse into the kernels, or None (time_benchmark skips it, models/fastkan.py:67-70)."""
+        return self.layernorm if getattr(self, "_use_ln", True) else None
+
     @staticmethod
     def kan_u_grouped(layers, x2d, n_heads):
         """LayerNorm of every (projection, head) slice: normalise each head slice once, then apply

@@ -46,11 +46,39 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
 
 
+def test_fused_layernorm_query_is_host_only(lib):
+    """kanvit_layer_ln_fusable (FastKAN LayerNorm fusion, KANVIT_FLAG_FUSED_LN) is a pure host function: the headline
+    geometries qualify, ragged / tiny / non-RBF ones do not, and the flag is refused where it cannot apply."""
+    from kanvit import _lib
+
+    def desc(**kw):
+        base = dict(family=_lib.RBF, groups=18, x_group_mod=6, I=64, O=64, G=8, has_base=1, rbf_inv_h=1.75, M=25216,
+                    ldx=384, ldu=1152, ldy=1152, bparam_stride=8 + 128, ln_eps=1e-5)
+        base.update(kw)
+        return _lib.LayerDesc(**base)
+
+    assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc())) == 1                         # ViT-S q|k|v
+    assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(groups=1, x_group_mod=1, I=768, O=384, ldx=768, ldu=768,
+                                                         ldy=384))) == 1                  # ViT-S patch embedding
+    assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(M=100))) == 0                    # too few rows for the register kernels
+    assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(I=50, ldx=300))) == 0            # ragged feature count
+    assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(has_base=0))) == 0
+    assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(family=_lib.CHEBY, G=5))) == 0
+    d = desc(family=_lib.CHEBY, G=5, flags=_lib.FLAG_FUSED_LN)
+    assert lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -22
+    assert b"FUSED_LN" in lib.kanvit_last_error()
+    d = desc(flags=_lib.FLAG_FUSED_LN, bparam_stride=8)
+    assert lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -22
+    assert b"gamma" in lib.kanvit_last_error()
+    d = desc(flags=_lib.FLAG_FUSED_LN, M=100)
+    assert lib.kanvit_layer_bwd_weight(ctypes.byref(d), None, None, None, None, None, None, 0, None) == -22
+
+
 def test_descriptor_layout_and_errors(lib):
     from kanvit import _lib
-    assert ctypes.sizeof(_lib.LayerDesc) == 10 * 4 + 5 * 8
+    assert ctypes.sizeof(_lib.LayerDesc) == 10 * 4 + 5 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.AttnDesc) == 8 * 4 + 12 * 8
-    assert lib.kanvit_abi_version() == 4
+    assert lib.kanvit_abi_version() == 5
     d = _lib.LayerDesc(family=99, groups=1, x_group_mod=1, I=4, O=3, G=1, M=6, ldx=4, ldy=3)
     rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
     assert rc == -22 and b"family" in lib.kanvit_last_error()

@@ -123,7 +123,9 @@ def test_patch_embedding_layer_bf16(fam, i, o, big):
     # so dx must match one of the two specified arithmetics -- bf16 operands, or exact
     assert min(maxrel(xg.grad, gx_t), maxrel(xg.grad, gx_e)) < TIGHT, (fam, "dx", maxrel(xg.grad, gx_t), maxrel(xg.grad, gx_e))
     for k, g in gp_t.items():
-        assert maxrel(got[k], g) < TIGHT, (fam, k, maxrel(got[k], g))
+        # FastKAN's layernorm.* gradients are column sums of du, i.e. products of the INPUT-gradient kernel: same rule as dx
+        err = min(maxrel(got[k], g), maxrel(got[k], gp_e[k])) if k.startswith("layernorm.") else maxrel(got[k], g)
+        assert err < TIGHT, (fam, k, err)
     assert 1e-5 < fro(y, y_e) < LOOSE, (fam, fro(y, y_e))
     assert fro(xg.grad, gx_e) < LOOSE, (fam, "dx", fro(xg.grad, gx_e))
     for k, g in gp_e.items():
