@@ -193,6 +193,19 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
                     const float* o, const float* lse, const float* d_o,
                     float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused feed-forward for the small geometries ---------------------------------------------
+ * y = relu(x W1^T + b1) W2^T + b2, the TransformerBlock's nn.Sequential(Linear, ReLU(inplace), Linear) (model.py:25-29,36),
+ * x[M][D], W1[F][D], b1[F], W2[D][F], b2[D] in nn.Linear's own layouts; fp32 products and sums.  Forward: one launch;
+ * backward (recomputes the hidden activations): dx[M][D], dW1[F][D], db1[F], dW2[D][F], db2[D], deterministic.
+ * Instantiated for the reference's default width only (D = 64, F = 256) and M <= kanvit_ff_small_max_rows().            */
+int kanvit_ff_small_supported(int D, int F);
+int64_t kanvit_ff_small_max_rows(void);
+int kanvit_ff_small_fwd(int64_t M, int D, int F, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        float* y, void* stream);
+size_t kanvit_ff_small_bwd_workspace(int64_t M, int D, int F);
+int kanvit_ff_small_bwd(int64_t M, int D, int F, const float* x, const float* w1, const float* b1, const float* w2, const float* dy,
+                        float* dx, float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- residual add + LayerNorm (the TransformerBlock assembly around the KAN / attention kernels) -------------------
  * Replaces the `x + ...` adds and the nn.LayerNorm calls of model.py:31-37 (TransformerBlock.forward) and their autograd
  * backward, two to four separate passes over [M, D] each in the reference, by one pass forward and one backward.

@@ -1778,10 +1778,10 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     return d->D <= 32 ? dispatch_fwd<1, false>(a, st) : dispatch_fwd<2, false>(a, st);
 }
 
-// rowsum(dO*O) [B*H*N] (rounded up to 16 bytes), then -- exact fp32 path with D in {32, 64} and N >= 64 only -- dS [B*H][NP][NP]
+// rowsum(dO*O) [B*H*N] (rounded up to 16 bytes), then -- exact fp32 path with D in {32, 64} only -- dS [B*H][NP][NP]
 static size_t attn_delta_bytes(const kanvit_attn_desc* d) { return (sizeof(float) * (size_t)d->B * d->H * d->N + 15) / 16 * 16; }
 static bool attn_ds_spill(const kanvit_attn_desc* d) {
-    return !(d->flags & KANVIT_FLAG_BF16_MFMA) && (d->D == 32 || d->D == 64) && d->N >= 64 && !d->causal && !kv_config().attn_no_ds &&
+    return !(d->flags & KANVIT_FLAG_BF16_MFMA) && (d->D == 32 || d->D == 64) && !d->causal && !kv_config().attn_no_ds &&
            !kv_config().attn_v1;
 }
 size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d) {

@@ -2774,7 +2774,11 @@ int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     if (a.O % (32 * nt)) return 1;
     const int nshare = a.groups / a.xmod;
-    const bool share3 = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare == 3 && nt <= 2;
+    // q|k|v sharing one basis evaluation (NSH = 3) triples the MFMA chain of every wave; when the launch has fewer
+    // work-groups than CUs (the small geometries: 50 row tiles x 2 heads) the chain length IS the kernel time, so each
+    // projection gets its own work-groups there and re-evaluates the basis
+    const bool share3 = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare == 3 && nt <= 2 &&
+                        ((a.M + BM - 1) / BM) * a.xmod >= N_CU;
     const int nsh = share3 ? 3 : 1;
     if ((a.O & 3) || (a.ldy & 3) || ((uintptr_t)a.y & 15) || ((uintptr_t)a.w & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return 1;
     const int wrow = 32 * nt * nsh, wrs = 256 / (8 * nt);
@@ -3217,11 +3221,12 @@ static void kv_config_load() {
     c.attn_v2 = flag("KANVIT_ATTN_V2");
     c.attn_no_ds = flag("KANVIT_ATTN_NO_DS");
     c.attn_grid = num("KANVIT_ATTN_GRID");
+    c.ff_grid = num("KANVIT_FF_GRID");
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d",
-             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic);
+             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
+             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }

@@ -49,10 +49,11 @@ struct KvConfig {
     int attn_v1;         // KANVIT_ATTN_V1         first-form attention kernels
     int attn_v2;         // KANVIT_ATTN_V2         second-form fp32 attention kernels (round 1) instead of the pipelined third form
     int attn_no_ds;      // KANVIT_ATTN_NO_DS      fp32 attention backward without the dS hand-off
+    int ff_grid;         // KANVIT_FF_GRID         work-groups of the fused small feed-forward backward (tuning; 0 = default)
     int attn_grid;       // KANVIT_ATTN_GRID       work-groups of the persistent attention kernels (tuning; 0 = one round of resident ones)
     int bf16_nsh;        // KANVIT_BF16_NSH        LDS-tile bf16 forward: groups per basis tile (tuning)
     int bf16_ic;         // KANVIT_BF16_IC         LDS-tile bf16 forward: feature chunk cap (tuning)
-    char text[352];
+    char text[384];
 };
 const KvConfig& kv_config();
 

@@ -60,6 +60,11 @@ SYMBOLS = {
     "kanvit_device_count": (C.c_int, []),
     "kanvit_config": (C.c_char_p, []),
     "kanvit_config_reload": (C.c_int, []),
+    "kanvit_ff_small_supported": (C.c_int, [C.c_int, C.c_int]),
+    "kanvit_ff_small_max_rows": (C.c_int64, []),
+    "kanvit_ff_small_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7),
+    "kanvit_ff_small_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "kanvit_ff_small_bwd": (C.c_int, [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 11 + [C.c_size_t, C.c_void_p]),
     "kanvit_layer_ln_fusable": (C.c_int, [C.POINTER(LayerDesc)]),
     "kanvit_layer_ln_bwd_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_ln_bwd": (C.c_int, [C.POINTER(LayerDesc)] + [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p]),

@@ -160,10 +160,67 @@ class _FFSplitFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2
 
 
+class _FFSmallFn(torch.autograd.Function):
+    """Linear -> ReLU -> Linear of the small geometries (d = 64, 4d = 256: the reference's own defaults, model.py:49 and
+    train.py:18-20) as ONE forward launch and ONE backward launch + an ordered reduce (csrc/ff_small.hip, SURVEY.md section
+    8(f)1) instead of 2 + ~14 stock launches of ~5 us each.  fp32 products and sums on the matrix cores; the backward
+    recomputes the hidden activations instead of saving [M, 4d]."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w1, b1, w2, b2):
+        from . import _lib, ops
+        x, w1, b1, w2, b2 = (t.contiguous() for t in (x, w1, b1, w2, b2))
+        M, D = x.shape
+        F_ = w1.shape[0]
+        y = torch.empty(M, D, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device), ops._timed("ff_small_fwd", 4 * M * D * F_, 4 * (2 * M * D + 2 * D * F_)):
+            _lib.check(_lib.lib().kanvit_ff_small_fwd(M, D, F_, ops._ptr(x), ops._ptr(w1), ops._ptr(b1), ops._ptr(w2), ops._ptr(b2),
+                                                      ops._ptr(y), ops._stream()), "kanvit_ff_small_fwd")
+        ctx.save_for_backward(x, w1, b1, w2)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        from . import _lib, ops
+        import ctypes as C
+        x, w1, b1, w2 = ctx.saved_tensors
+        M, D = x.shape
+        F_ = w1.shape[0]
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        dw1, db1, dw2, db2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty(D, device=x.device, dtype=torch.float32)
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            nbytes = int(L.kanvit_ff_small_bwd_workspace(M, D, F_))
+            ws = ops._workspace(nbytes, x.device)
+            with ops._timed("ff_small_bwd", 8 * M * D * F_, 4 * (3 * M * D + 4 * D * F_)):
+                _lib.check(L.kanvit_ff_small_bwd(M, D, F_, ops._ptr(x), ops._ptr(w1), ops._ptr(b1), ops._ptr(w2), ops._ptr(dy), ops._ptr(dx),
+                                                 ops._ptr(dw1), ops._ptr(db1), ops._ptr(dw2), ops._ptr(db2), ops._ptr(ws), C.c_size_t(nbytes),
+                                                 ops._stream()), "kanvit_ff_small_bwd")
+        return dx, dw1, db1, dw2, db2
+
+
+def _ff_small_ok(x, lin1, lin2) -> bool:
+    import os
+    if os.environ.get("KANVIT_NO_FF_SMALL") or not x.is_cuda or x.dtype != torch.float32 or lin1.bias is None or lin2.bias is None:
+        return False
+    if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32:
+        return False                       # bf16 autocast keeps the stock bf16 GEMMs
+    if lin1.weight.dtype != torch.float32 or lin2.out_features != lin1.in_features or lin2.in_features != lin1.out_features:
+        return False
+    from . import _lib
+    L = _lib.lib()
+    return bool(L.kanvit_ff_small_supported(lin1.in_features, lin1.out_features)) and 0 < x.shape[0] <= int(L.kanvit_ff_small_max_rows())
+
+
 def feed_forward(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear) -> torch.Tensor:
     """lin2(relu(lin1(x))) for a 2-D x: the stock-GEMM path (`dense`) or, when FF_MODE == "bf16x3" and the shapes allow
     it (CUDA, fp32 parameters, widths multiples of 8, biases present, M divisible into slabs), the split-bf16 path."""
     import os
+    if _ff_small_ok(x, lin1, lin2):
+        return _FFSmallFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
     mode = os.environ.get("KANVIT_FF", FF_MODE)
     if (mode == "bf16x3" and x.is_cuda and lin1.bias is not None and lin2.bias is not None and
             lin1.in_features % 8 == 0 and lin1.out_features % 8 == 0 and lin2.out_features % 8 == 0 and
