@@ -205,6 +205,16 @@ int kanvit_ff_small_fwd(int64_t M, int D, int F, const float* x, const float* w1
 size_t kanvit_ff_small_bwd_workspace(int64_t M, int D, int F);
 int kanvit_ff_small_bwd(int64_t M, int D, int F, const float* x, const float* w1, const float* b1, const float* w2, const float* dy,
                         float* dx, float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the block's second LayerNorm fused in front (model.py:36  x = x + FF(LN2(x)),  x = x_in + delta):
+ *   fwd: s = x + delta (delta may be NULL), y = FF(LayerNorm(s; gamma, beta, eps)); writes s[M][D], mean[M], rstd[M], y[M][D]
+ *   bwd: ds = ds_in (may be NULL) + LayerNorm-backward(FF-backward(dy))  -- the gradient of x and of delta alike --
+ *        dgamma[D], dbeta[D], dW1, db1, dW2, db2.  Workspace: kanvit_ff_small_bwd_workspace.                         */
+int kanvit_lnff_small_fwd(int64_t M, int D, int F, float eps, const float* x, const float* delta, const float* gamma, const float* beta,
+                          const float* w1, const float* b1, const float* w2, const float* b2, float* s, float* mean, float* rstd, float* y,
+                          void* stream);
+int kanvit_lnff_small_bwd(int64_t M, int D, int F, const float* s, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          const float* w1, const float* b1, const float* w2, const float* dy, const float* ds_in, float* ds, float* dgamma,
+                          float* dbeta, float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- residual add + LayerNorm (the TransformerBlock assembly around the KAN / attention kernels) -------------------
  * Replaces the `x + ...` adds and the nn.LayerNorm calls of model.py:31-37 (TransformerBlock.forward) and their autograd

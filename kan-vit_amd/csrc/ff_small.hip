@@ -21,6 +21,8 @@
 #include "../../include/kanvit.h"
 #include "kanvit_common.h"
 
+#include <initializer_list>
+
 namespace {
 
 struct FfArgs {
@@ -32,9 +34,18 @@ struct FfArgs {
     const float* dy;
     float* y;
     float* dx;
-    float* part;      // [work-groups][2*F*D + F + D]: dW1[F][D] | dW2^T[F][D] | db1[F] | db2[D]
+    float* part;      // [work-groups][2*F*D + F + 3*D]: dW1[F][D] | dW2^T[F][D] | db1[F] | db2[D] | dgamma[D] | dbeta[D]
     long long M;
     int tiles;
+    // LN variants: the block's second LayerNorm fused in front (model.py:36: x = x + FF(LN2(x)) with x = x_in + delta)
+    const float* delta;   // forward: added to x first (may be null)
+    const float* gamma;
+    const float* beta;
+    float* s;             // forward out / backward in: s = x + delta [M][D]
+    float* mean;          // forward out / backward in: row statistics of s
+    float* rstd;
+    const float* ds_in;   // backward: gradient arriving on s from later uses (may be null)
+    float eps;
 };
 
 template <int N>
@@ -67,7 +78,7 @@ __device__ __forceinline__ f32x16 ff_hidden_tile(const float* __restrict__ w1, i
     return acc;
 }
 
-template <int D, int F, int NW>
+template <int D, int F, int NW, bool LN>
 __global__ __launch_bounds__(64 * NW) void ff_small_fwd_kernel(const FfArgs a) {
     constexpr int NTH = F / (32 * NW), NDT = D / 32, DH = D / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
@@ -79,6 +90,41 @@ __global__ __launch_bounds__(64 * NW) void ff_small_fwd_kernel(const FfArgs a) {
         if (mr >= a.M) mr = a.M - 1;
         float xr[DH];
         ff_load_row<DH>(xr, a.x + mr * D + hf * DH);
+        if constexpr (LN) {       // s = x + delta; h2 = LayerNorm(s) -- every wave forms it for its own operand, wave 0 stores s and the statistics
+            if (a.delta) {
+                float dr[DH];
+                ff_load_row<DH>(dr, a.delta + mr * D + hf * DH);
+#pragma unroll
+                for (int i = 0; i < DH; ++i) xr[i] += dr[i];
+            }
+            const bool owner = wave == 0 && m0 + l31 < a.M;
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < DH / 4; ++i) {
+                    const f32x4 v = {xr[4 * i], xr[4 * i + 1], xr[4 * i + 2], xr[4 * i + 3]};
+                    *reinterpret_cast<f32x4*>(a.s + mr * D + hf * DH + 4 * i) = v;
+                }
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DH; ++i) sum += xr[i];
+            sum += __shfl_xor(sum, 32);
+            const float mu = sum * (1.0f / D);
+            float sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DH; ++i) sq += (xr[i] - mu) * (xr[i] - mu);       // two-pass: no E[x^2] - E[x]^2 cancellation
+            sq += __shfl_xor(sq, 32);
+            const float rs = rsqrtf(sq * (1.0f / D) + a.eps);
+            if (owner && hf == 0) {
+                a.mean[mr] = mu;
+                a.rstd[mr] = rs;
+            }
+            float gr[DH], br[DH];
+            ff_load_row<DH>(gr, a.gamma + hf * DH);
+            ff_load_row<DH>(br, a.beta + hf * DH);
+#pragma unroll
+            for (int i = 0; i < DH; ++i) xr[i] = (xr[i] - mu) * rs * gr[i] + br[i];
+        }
         f32x16 h[NTH];
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
@@ -127,8 +173,9 @@ __global__ __launch_bounds__(64 * NW) void ff_small_fwd_kernel(const FfArgs a) {
     }
 }
 
-template <int D, int F, int NW>
+template <int D, int F, int NW, bool LN>
 __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
+    static_assert(!LN || 32 * (D / 4) == 64 * NW, "the LayerNorm backward maps one float4 of the dx tile to each thread");
     constexpr int NTH = F / (32 * NW), NDT = D / 32, DH = D / 2, DS = D + 32;
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31_ = lane & 31, hf_ = lane >> 5;
@@ -143,6 +190,7 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
     f32x16 gw1[NTH][NDT], gw2[NTH][NDT];   // dW1[n][k], dW2^T[n][o] of this wave's hidden slice
     float gb1[NTH][16];
     float gb2 = 0.0f;
+    f32x4 gdg = {0.0f, 0.0f, 0.0f, 0.0f}, gdb = gdg;      // LN: column sums for dgamma / dbeta (thread = 4 columns, fixed over tiles)
 #pragma unroll
     for (int t = 0; t < NTH; ++t) {
 #pragma unroll
@@ -165,26 +213,29 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
         int l31 = l31_, hf = hf_;
         asm volatile("" : "+s"(pw1), "+s"(pw2), "+s"(pb1), "+v"(l31), "+v"(hf));
         const long long m0 = (long long)tile * 32;
-        const bool live = m0 + l31 < a.M;
-        const long long mr = live ? m0 + l31 : a.M - 1;
-        // stage the x and dy tiles (the weight gradients contract over rows: lane = column there)
+        // stage the x and dy tiles (rows past M: zero); LN: x is rebuilt from s and its row statistics
         for (int idx = tid; idx < 32 * (D / 4); idx += NT) {
             const int m = idx / (D / 4), c = idx % (D / 4);
             f32x4 xv = {0.0f, 0.0f, 0.0f, 0.0f}, dv = xv;
             if (m0 + m < a.M) {
-                xv = *reinterpret_cast<const f32x4*>(a.x + (m0 + m) * D + 4 * c);
                 dv = *reinterpret_cast<const f32x4*>(a.dy + (m0 + m) * D + 4 * c);
+                if constexpr (LN) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(a.s + (m0 + m) * D + 4 * c);
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gamma + 4 * c), bv = *reinterpret_cast<const f32x4*>(a.beta + 4 * c);
+                    const float mu = a.mean[m0 + m], rs = a.rstd[m0 + m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = (sv[e] - mu) * rs * gv[e] + bv[e];
+                } else {
+                    xv = *reinterpret_cast<const f32x4*>(a.x + (m0 + m) * D + 4 * c);
+                }
             }
             *reinterpret_cast<f32x4*>(xs + m * DS + 4 * c) = xv;
             *reinterpret_cast<f32x4*>(dys + m * DS + 4 * c) = dv;
         }
-        float xr[DH], dyr[DH];
-        ff_load_row<DH>(xr, a.x + mr * D + hf * DH);
-        ff_load_row<DH>(dyr, a.dy + mr * D + hf * DH);
-        if (!live) {
-#pragma unroll
-            for (int s = 0; s < DH; ++s) dyr[s] = 0.0f;
-        }
+        __syncthreads();
+        float xr[DH], dyr[DH];      // this lane's half rows (operands of the row-indexed products) come back out of the staged tiles
+        ff_load_row<DH>(xr, xs + l31 * DS + hf * DH);
+        ff_load_row<DH>(dyr, dys + l31 * DS + hf * DH);
         f32x16 dxacc[NDT];
 #pragma unroll
         for (int kt = 0; kt < NDT; ++kt) dxacc[kt] = ff_zero16();
@@ -239,8 +290,9 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
         __syncthreads();
         for (int idx = tid; idx < 32 * (D / 4); idx += NT) {
             const int m = idx / (D / 4), c = idx % (D / 4);
-            if (m0 + m < a.M) {
-                f32x4 v;
+            const bool rowok = m0 + m < a.M;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (rowok || LN) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float s = red[(4 * c + e) * 33 + m];
@@ -248,7 +300,42 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
                     for (int w = 1; w < NW; ++w) s += red[(w * D + 4 * c + e) * 33 + m];
                     v[e] = s;
                 }
-                *reinterpret_cast<f32x4*>(a.dx + (m0 + m) * D + 4 * c) = v;
+            }
+            if constexpr (LN) {
+                // v = d loss / d LN2(s) for 4 columns of row m; the 16 lanes of a row meet by xor-shuffles (every thread is here: one
+                // float4 each).  ds = rstd * (v*g - mean(v*g) - xhat * mean(v*g*xhat)) + the gradient arriving on s itself.
+                f32x4 sv = {0.0f, 0.0f, 0.0f, 0.0f}, xh, gy;
+                float mu = 0.0f, rs = 0.0f;
+                if (rowok) {
+                    sv = *reinterpret_cast<const f32x4*>(a.s + (m0 + m) * D + 4 * c);
+                    mu = a.mean[m0 + m];
+                    rs = a.rstd[m0 + m];
+                }
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gamma + 4 * c);
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[e] = (sv[e] - mu) * rs;
+                    gy[e] = v[e] * gv[e];
+                    t1 += gy[e];
+                    t2 += gy[e] * xh[e];
+                    gdg[e] += v[e] * xh[e];
+                    gdb[e] += v[e];
+                }
+#pragma unroll
+                for (int o = 1; o < D / 4; o <<= 1) {
+                    t1 += __shfl_xor(t1, o);
+                    t2 += __shfl_xor(t2, o);
+                }
+                if (rowok) {
+                    f32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = rs * (gy[e] - t1 * (1.0f / D) - xh[e] * t2 * (1.0f / D));
+                    if (a.ds_in) o4 += *reinterpret_cast<const f32x4*>(a.ds_in + (m0 + m) * D + 4 * c);
+                    *reinterpret_cast<f32x4*>(a.dx + (m0 + m) * D + 4 * c) = o4;
+                }
+            } else {
+                if (rowok) *reinterpret_cast<f32x4*>(a.dx + (m0 + m) * D + 4 * c) = v;
             }
         }
         if (tid < D) {
@@ -276,7 +363,27 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
     }
 
     const int l31 = l31_, hf = hf_;
-    float* part = a.part + (size_t)blockIdx.x * (2 * F * D + F + D);
+    float* part = a.part + (size_t)blockIdx.x * (2 * F * D + F + 3 * D);
+    if constexpr (LN) {       // dgamma / dbeta: thread (m, c) -> the 4 rows of a wave by shuffles, the NW waves through LDS (red is free now)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gdg[e] += __shfl_xor(gdg[e], 16);
+            gdg[e] += __shfl_xor(gdg[e], 32);
+            gdb[e] += __shfl_xor(gdb[e], 16);
+            gdb[e] += __shfl_xor(gdb[e], 32);
+        }
+        if (lane < 16) {
+            *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * D + 4 * lane) = gdg;
+            *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * D + 4 * lane) = gdb;
+        }
+        __syncthreads();
+        if (tid < 2 * D) {
+            float t = red[tid];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t += red[w * 2 * D + tid];
+            part[2 * F * D + F + D + tid] = t;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NTH; ++t) {
 #pragma unroll
@@ -301,8 +408,10 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
 // out[idx] = sum_p part[p][idx] in fixed order (8 interleaved sub-sums joined in order), scattered to dW1 / dW2 / db1 / db2
 template <int D, int F>
 __global__ __launch_bounds__(256) void ff_small_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw1,
-                                                              float* __restrict__ dw2, float* __restrict__ db1, float* __restrict__ db2) {
-    constexpr int PART = 2 * F * D + F + D;
+                                                              float* __restrict__ dw2, float* __restrict__ db1, float* __restrict__ db2,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int STRIDE = 2 * F * D + F + 3 * D;
+    const int PART = dgamma ? STRIDE : STRIDE - 2 * D;
     __shared__ float sub[8][33];
     const int cl = threadIdx.x & 31, k = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + cl;
@@ -312,11 +421,11 @@ __global__ __launch_bounds__(256) void ff_small_reduce_kernel(const float* __res
         for (; p + 24 < nparts; p += 32) {
             float t[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = part[(size_t)(p + 8 * j) * PART + idx];
+            for (int j = 0; j < 4; ++j) t[j] = part[(size_t)(p + 8 * j) * STRIDE + idx];
 #pragma unroll
             for (int j = 0; j < 4; ++j) s += t[j];
         }
-        for (; p < nparts; p += 8) s += part[(size_t)p * PART + idx];
+        for (; p < nparts; p += 8) s += part[(size_t)p * STRIDE + idx];
     }
     sub[k][cl] = s;
     __syncthreads();
@@ -329,7 +438,9 @@ __global__ __launch_bounds__(256) void ff_small_reduce_kernel(const float* __res
             const int j = idx - F * D;
             dw2[(size_t)(j % D) * F + j / D] = t;
         } else if (idx < 2 * F * D + F) db1[idx - 2 * F * D] = t;
-        else db2[idx - 2 * F * D - F] = t;
+        else if (idx < 2 * F * D + F + D) db2[idx - 2 * F * D - F] = t;
+        else if (idx < 2 * F * D + F + 2 * D) dgamma[idx - 2 * F * D - F - D] = t;
+        else dbeta[idx - 2 * F * D - F - 2 * D] = t;
     }
 }
 
@@ -348,6 +459,38 @@ int ff_check(const char* who, long long M, int D, int F) {
     return 0;
 }
 
+constexpr int FF_PART = 2 * FF_F * FF_D + FF_F + 3 * FF_D;
+
+template <bool LN>
+int ff_launch_fwd(FfArgs& a, hipStream_t st) {
+    a.tiles = (int)((a.M + 31) / 32);
+    KV_ALLOW_LDS(160 * 1024, (ff_small_fwd_kernel<FF_D, FF_F, FF_NW, LN>));
+    hipLaunchKernelGGL((ff_small_fwd_kernel<FF_D, FF_F, FF_NW, LN>), dim3(a.tiles < 1024 ? a.tiles : 1024), dim3(64 * FF_NW),
+                       sizeof(float) * FF_NW * FF_D * 33, st, a);
+    KV_LAUNCH_CHECK("ff_small_fwd_kernel");
+    return 0;
+}
+
+template <bool LN>
+int ff_launch_bwd(FfArgs& a, float* dw1, float* db1, float* dw2, float* db2, float* dgamma, float* dbeta, hipStream_t st) {
+    a.tiles = (int)((a.M + 31) / 32);
+    const int grid = ff_bwd_grid(a.M);
+    KV_ALLOW_LDS(160 * 1024, (ff_small_bwd_kernel<FF_D, FF_F, FF_NW, LN>));
+    hipLaunchKernelGGL((ff_small_bwd_kernel<FF_D, FF_F, FF_NW, LN>), dim3(grid), dim3(64 * FF_NW), FF_BWD_LDS, st, a);
+    KV_LAUNCH_CHECK("ff_small_bwd_kernel");
+    const int outs = LN ? FF_PART : FF_PART - 2 * FF_D;
+    hipLaunchKernelGGL((ff_small_reduce_kernel<FF_D, FF_F>), dim3((outs + 31) / 32), dim3(256), 0, st, (const float*)a.part, grid, dw1, dw2, db1, db2,
+                       LN ? dgamma : (float*)nullptr, LN ? dbeta : (float*)nullptr);
+    KV_LAUNCH_CHECK("ff_small_reduce_kernel");
+    return 0;
+}
+
+bool ff_misaligned(std::initializer_list<const void*> ps, unsigned mask = 15) {
+    for (const void* q : ps)
+        if (q && ((uintptr_t)q & mask)) return true;
+    return false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -360,20 +503,15 @@ int kanvit_ff_small_fwd(int64_t M, int D, int F, const float* x, const float* w1
     if (int rc = ff_check("kanvit_ff_small_fwd", M, D, F)) return rc;
     if (M == 0) return 0;
     if (!x || !w1 || !b1 || !w2 || !b2 || !y) return kv_fail(KANVIT_EINVAL, "kanvit_ff_small_fwd: null argument");
-    if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)w2 | (uintptr_t)b2 | (uintptr_t)y) & 15)
-        return kv_fail(KANVIT_EINVAL, "kanvit_ff_small_fwd: pointers must be 16-byte aligned");
+    if (ff_misaligned({x, w1, b1, w2, b2, y})) return kv_fail(KANVIT_EINVAL, "kanvit_ff_small_fwd: pointers must be 16-byte aligned");
     FfArgs a{};
-    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.M = M; a.tiles = (int)((M + 31) / 32);
-    KV_ALLOW_LDS(160 * 1024, (ff_small_fwd_kernel<FF_D, FF_F, FF_NW>));
-    hipLaunchKernelGGL((ff_small_fwd_kernel<FF_D, FF_F, FF_NW>), dim3(a.tiles < 1024 ? a.tiles : 1024), dim3(64 * FF_NW),
-                       sizeof(float) * FF_NW * FF_D * 33, (hipStream_t)stream, a);
-    KV_LAUNCH_CHECK("ff_small_fwd_kernel");
-    return 0;
+    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.y = y; a.M = M;
+    return ff_launch_fwd<false>(a, (hipStream_t)stream);
 }
 
 size_t kanvit_ff_small_bwd_workspace(int64_t M, int D, int F) {
     if (M <= 0 || D != FF_D || F != FF_F) return 0;
-    return sizeof(float) * (size_t)ff_bwd_grid(M) * (2 * FF_F * FF_D + FF_F + FF_D);
+    return sizeof(float) * (size_t)ff_bwd_grid(M) * FF_PART;
 }
 
 int kanvit_ff_small_bwd(int64_t M, int D, int F, const float* x, const float* w1, const float* b1, const float* w2, const float* dy,
@@ -389,21 +527,54 @@ int kanvit_ff_small_bwd(int64_t M, int D, int F, const float* x, const float* w1
         return 0;
     }
     if (!x || !w1 || !b1 || !w2 || !dy || !dx) return kv_fail(KANVIT_EINVAL, "kanvit_ff_small_bwd: null argument");
-    if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)w2 | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)workspace) & 15)
-        return kv_fail(KANVIT_EINVAL, "kanvit_ff_small_bwd: pointers must be 16-byte aligned");
+    if (ff_misaligned({x, w1, b1, w2, dy, dx, workspace})) return kv_fail(KANVIT_EINVAL, "kanvit_ff_small_bwd: pointers must be 16-byte aligned");
     const size_t need = kanvit_ff_small_bwd_workspace(M, D, F);
     if (!workspace || workspace_bytes < need)
         return kv_fail(KANVIT_ENOMEM, "kanvit_ff_small_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
     FfArgs a{};
-    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.dy = dy; a.dx = dx; a.part = (float*)workspace; a.M = M; a.tiles = (int)((M + 31) / 32);
-    const int grid = ff_bwd_grid(M);
-    KV_ALLOW_LDS(160 * 1024, (ff_small_bwd_kernel<FF_D, FF_F, FF_NW>));
-    hipLaunchKernelGGL((ff_small_bwd_kernel<FF_D, FF_F, FF_NW>), dim3(grid), dim3(64 * FF_NW), FF_BWD_LDS, st, a);
-    KV_LAUNCH_CHECK("ff_small_bwd_kernel");
-    constexpr int PART = 2 * FF_F * FF_D + FF_F + FF_D;
-    hipLaunchKernelGGL((ff_small_reduce_kernel<FF_D, FF_F>), dim3((PART + 31) / 32), dim3(256), 0, st, (const float*)workspace, grid, dw1, dw2, db1, db2);
-    KV_LAUNCH_CHECK("ff_small_reduce_kernel");
-    return 0;
+    a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.dy = dy; a.dx = dx; a.part = (float*)workspace; a.M = M;
+    return ff_launch_bwd<false>(a, dw1, db1, dw2, db2, nullptr, nullptr, st);
+}
+
+/* s = x + delta;  y = FF(LayerNorm(s)): the second half of a TransformerBlock up to (not including) the residual add of y */
+int kanvit_lnff_small_fwd(int64_t M, int D, int F, float eps, const float* x, const float* delta, const float* gamma, const float* beta,
+                          const float* w1, const float* b1, const float* w2, const float* b2, float* s, float* mean, float* rstd, float* y,
+                          void* stream) {
+    if (int rc = ff_check("kanvit_lnff_small_fwd", M, D, F)) return rc;
+    if (M == 0) return 0;
+    if (!x || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !s || !mean || !rstd || !y) return kv_fail(KANVIT_EINVAL, "kanvit_lnff_small_fwd: null argument");
+    if (ff_misaligned({x, delta, gamma, beta, w1, b1, w2, b2, s, y})) return kv_fail(KANVIT_EINVAL, "kanvit_lnff_small_fwd: pointers must be 16-byte aligned");
+    FfArgs a{};
+    a.x = x; a.delta = delta; a.gamma = gamma; a.beta = beta; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.s = s; a.mean = mean; a.rstd = rstd; a.y = y; a.M = M; a.eps = eps;
+    return ff_launch_fwd<true>(a, (hipStream_t)stream);
+}
+
+/* ds = ds_in + LayerNorm-backward(FF-backward(dy)) (the gradient of x AND of delta), plus every parameter gradient */
+int kanvit_lnff_small_bwd(int64_t M, int D, int F, const float* s, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          const float* w1, const float* b1, const float* w2, const float* dy, const float* ds_in, float* ds, float* dgamma,
+                          float* dbeta, float* dw1, float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = ff_check("kanvit_lnff_small_bwd", M, D, F)) return rc;
+    if (!dw1 || !db1 || !dw2 || !db2 || !dgamma || !dbeta) return kv_fail(KANVIT_EINVAL, "kanvit_lnff_small_bwd: null gradient output");
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        KV_HIP_CHECK(hipMemsetAsync(dw1, 0, sizeof(float) * F * D, st));
+        KV_HIP_CHECK(hipMemsetAsync(dw2, 0, sizeof(float) * F * D, st));
+        KV_HIP_CHECK(hipMemsetAsync(db1, 0, sizeof(float) * F, st));
+        KV_HIP_CHECK(hipMemsetAsync(db2, 0, sizeof(float) * D, st));
+        KV_HIP_CHECK(hipMemsetAsync(dgamma, 0, sizeof(float) * D, st));
+        KV_HIP_CHECK(hipMemsetAsync(dbeta, 0, sizeof(float) * D, st));
+        return 0;
+    }
+    if (!s || !mean || !rstd || !gamma || !beta || !w1 || !b1 || !w2 || !dy || !ds) return kv_fail(KANVIT_EINVAL, "kanvit_lnff_small_bwd: null argument");
+    if (ff_misaligned({s, gamma, beta, w1, b1, w2, dy, ds_in, ds, workspace})) return kv_fail(KANVIT_EINVAL, "kanvit_lnff_small_bwd: pointers must be 16-byte aligned");
+    const size_t need = kanvit_ff_small_bwd_workspace(M, D, F);
+    if (!workspace || workspace_bytes < need)
+        return kv_fail(KANVIT_ENOMEM, "kanvit_lnff_small_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+    FfArgs a{};
+    a.s = const_cast<float*>(s); a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.gamma = gamma; a.beta = beta;
+    a.w1 = w1; a.b1 = b1; a.w2 = w2; a.dy = dy; a.ds_in = ds_in; a.dx = ds; a.part = (float*)workspace; a.M = M;
+    return ff_launch_bwd<true>(a, dw1, db1, dw2, db2, dgamma, dbeta, st);
 }
 
 }  // extern "C"

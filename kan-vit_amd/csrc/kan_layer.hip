@@ -3127,6 +3127,13 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     p.tiles_per_bg = (p.shared ? nshare : 1) * (d->O / 32);
     p.nfb = d->I / 32;
     p.nos = (p.tiles_per_bg + p.nt - 1) / p.nt;
+    // Small launches (the T / C geometries: 6400 rows, 2 heads): even at the shortest slab (64 tokens) the wave units cannot
+    // fill the chip, and a wave's MFMA chain (tokens x GP x NOT) IS the kernel time.  One column tile per wave instead of
+    // three: three times the waves, a third of the chain each; the basis is re-evaluated per wave (cheap against the chain).
+    if (fam == KANVIT_CHEBY && p.nt == 3 && (long long)p.nbg * p.nfb * p.nos * (d->M / 64) < 4LL * N_CU) {
+        p.nt = 1;
+        p.nos = p.tiles_per_bg;
+    }
     // one live wave per SIMD (the accumulator block fills the register file): size the slab count so that the live waves
     // (work-groups whose 2x2 wave grid is only partly populated retire their idle waves at once) cover the chip r times
     const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
@@ -3176,7 +3183,7 @@ int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t
 int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
     switch (family) {
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
-        case KANVIT_CHEBY: return launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
+        case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
         case KANVIT_BSPLINE: return launch_bwd_weight_reg<KV_BSPLINE, 9, 2>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:

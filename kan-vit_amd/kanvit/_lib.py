@@ -65,6 +65,8 @@ SYMBOLS = {
     "kanvit_ff_small_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7),
     "kanvit_ff_small_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "kanvit_ff_small_bwd": (C.c_int, [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 11 + [C.c_size_t, C.c_void_p]),
+    "kanvit_lnff_small_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 13),
+    "kanvit_lnff_small_bwd": (C.c_int, [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 18 + [C.c_size_t, C.c_void_p]),
     "kanvit_layer_ln_fusable": (C.c_int, [C.POINTER(LayerDesc)]),
     "kanvit_layer_ln_bwd_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_ln_bwd": (C.c_int, [C.POINTER(LayerDesc)] + [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p]),

@@ -8,6 +8,8 @@ the token axis into S slabs -- one batched GEMM into [S, N, K] partials plus an 
 slab-then-reduce scheme the KAN weight-gradient kernel uses -- fills the chip: 0.83 ms, 143 TFLOP/s
 (tools/probe_wgrad.py).  Deterministic (fixed summation order), and slightly MORE accurate than the single long
 contraction."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -200,6 +202,71 @@ class _FFSmallFn(torch.autograd.Function):
                                                  ops._ptr(dw1), ops._ptr(db1), ops._ptr(dw2), ops._ptr(db2), ops._ptr(ws), C.c_size_t(nbytes),
                                                  ops._stream()), "kanvit_ff_small_bwd")
         return dx, dw1, db1, dw2, db2
+
+
+class _LnFFSmallFn(torch.autograd.Function):
+    """(x, delta | None, LN2, FF) -> (s = x + delta, FF(LayerNorm(s))): the second half of a small-geometry TransformerBlock
+    (model.py:36) in ONE forward launch; backward ONE launch + the ordered reduce, returning d s (the gradient of x and of
+    delta), d gamma, d beta and the four feed-forward parameter gradients (csrc/ff_small.hip, LN variants)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, delta, gamma, beta, w1, b1, w2, b2, eps):
+        from . import _lib, ops
+        D = x.shape[-1]
+        x2 = x.contiguous().view(-1, D)
+        d2 = None if delta is None else delta.contiguous().view(-1, D)
+        gamma, beta, w1, b1, w2, b2 = (t.contiguous() for t in (gamma, beta, w1, b1, w2, b2))
+        M, F_ = x2.shape[0], w1.shape[0]
+        s = torch.empty_like(x2)
+        y = torch.empty_like(x2)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device), ops._timed("ff_small_fwd", 4 * M * D * F_, 4 * (4 * M * D + 2 * D * F_)):
+            _lib.check(_lib.lib().kanvit_lnff_small_fwd(M, D, F_, float(eps), ops._ptr(x2), ops._ptr(d2), ops._ptr(gamma), ops._ptr(beta),
+                                                        ops._ptr(w1), ops._ptr(b1), ops._ptr(w2), ops._ptr(b2), ops._ptr(s), ops._ptr(mean),
+                                                        ops._ptr(rstd), ops._ptr(y), ops._stream()), "kanvit_lnff_small_fwd")
+        ctx.save_for_backward(s, mean, rstd, gamma, beta, w1, b1, w2)
+        ctx.has_delta = delta is not None
+        ctx.shape = x.shape
+        return s.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gs, gy):
+        from . import _lib, ops
+        import ctypes as C
+        s, mean, rstd, gamma, beta, w1, b1, w2 = ctx.saved_tensors
+        M, D = s.shape
+        F_ = w1.shape[0]
+        gy2 = gy.contiguous().view(M, D).float() if gy is not None else torch.zeros_like(s)
+        gs2 = None if gs is None else gs.contiguous().view(M, D).float()
+        ds = torch.empty_like(s)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        dw1, db1, dw2, db2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty(D, device=s.device, dtype=torch.float32)
+        L = _lib.lib()
+        with torch.cuda.device(s.device):
+            nbytes = int(L.kanvit_ff_small_bwd_workspace(M, D, F_))
+            ws = ops._workspace(nbytes, s.device)
+            with ops._timed("ff_small_bwd", 8 * M * D * F_, 4 * (5 * M * D + 4 * D * F_)):
+                _lib.check(L.kanvit_lnff_small_bwd(M, D, F_, ops._ptr(s), ops._ptr(mean), ops._ptr(rstd), ops._ptr(gamma), ops._ptr(beta),
+                                                   ops._ptr(w1), ops._ptr(b1), ops._ptr(w2), ops._ptr(gy2), ops._ptr(gs2), ops._ptr(ds),
+                                                   ops._ptr(dg), ops._ptr(db), ops._ptr(dw1), ops._ptr(db1), ops._ptr(dw2), ops._ptr(db2),
+                                                   ops._ptr(ws), C.c_size_t(nbytes), ops._stream()), "kanvit_lnff_small_bwd")
+        ds = ds.view(ctx.shape)
+        return ds, (ds if ctx.has_delta else None), dg, db, dw1, db1, dw2, db2, None
+
+
+def ln_feed_forward(x: torch.Tensor, delta, norm: torch.nn.LayerNorm, lin1: torch.nn.Linear, lin2: torch.nn.Linear):
+    """(s, f) with s = x + delta and f = lin2(relu(lin1(norm(s)))) -- model.py:36 without its final residual add.  One fused
+    launch for the small geometries; otherwise add_layernorm + feed_forward (the same arithmetic as two ops)."""
+    from . import ops
+    d = x.shape[-1]
+    if (norm.elementwise_affine and norm.bias is not None and tuple(norm.normalized_shape) == (d,) and (delta is None or delta.shape == x.shape)
+            and not os.environ.get("KANVIT_NO_LNFF") and _ff_small_ok(x.reshape(-1, d), lin1, lin2)):
+        return _LnFFSmallFn.apply(x, delta, norm.weight, norm.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm.eps)
+    s, h = ops.add_layernorm(x, delta, norm)
+    return s, feed_forward(h.reshape(-1, d), lin1, lin2).view(x.shape)
 
 
 def _ff_small_ok(x, lin1, lin2) -> bool:

@@ -40,6 +40,9 @@ class TransformerBlock(nn.Module):
         (stream after the attention add, this block's feed-forward output) -- same arithmetic as model.py:31-37:
             x = x + MSA(LN1(x));  x = x + FF(LN2(x))."""
         x, h1 = add_layernorm(x, pending, self.norm1)
+        if x.dim() == 3 and x.shape[-1] == 64:       # small geometries: residual add + LN2 + feed-forward in one launch (SURVEY 8(f)1)
+            from kanvit.dense import ln_feed_forward
+            return ln_feed_forward(x, self.attn(h1), self.norm2, self.ff[0], self.ff[2])
         x, h2 = add_layernorm(x, self.attn(h1), self.norm2)
         # Same three ops as self.ff (Linear -> ReLU(inplace) -> Linear, model.py:25-29), applied to the 2-D
         # (B*N, d) tensor: nn.Linear on 3-D input returns a VIEW, and an in-place ReLU on a view makes autograd

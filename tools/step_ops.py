@@ -33,7 +33,7 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
 ev = prof.events()
@@ -52,3 +52,9 @@ for e in cpu_ops:
         r[2][k.name[:60]] += 1
 for k, (n, us, names) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     print(f"{k[:46]:46s} launches {n:4d}  {us:8.1f} us   " + "; ".join(f"{a} x{b}" for a, b in sorted(names.items(), key=lambda t: -t[1])[:3]))
+
+print("\n-- aten::copy_ / aten::cat / aten::sum / aten::fill_ launches with shapes and the innermost python frame --")
+for e in cpu_ops:
+    if e.name in ("aten::copy_", "aten::cat", "aten::sum", "aten::fill_", "aten::add", "aten::mul") and getattr(e, "kernels", None):
+        frames = [f for f in (e.stack or []) if "kan-vit_amd" in f or "bench.py" in f]
+        print(f"{e.name:12s} {str(e.input_shapes)[:70]:70s} {frames[0][-90:] if frames else ''}")
