@@ -273,6 +273,8 @@ def _ff_small_ok(x, lin1, lin2) -> bool:
     import os
     if os.environ.get("KANVIT_NO_FF_SMALL") or not x.is_cuda or x.dtype != torch.float32 or lin1.bias is None or lin2.bias is None:
         return False
+    if os.environ.get("KANVIT_FF", FF_MODE) == "bf16x3":
+        return False                       # the opt-in split-product mode was asked for explicitly: it takes the feed-forward
     if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32:
         return False                       # bf16 autocast keeps the stock bf16 GEMMs
     if lin1.weight.dtype != torch.float32 or lin2.out_features != lin1.in_features or lin2.in_features != lin1.out_features:

@@ -104,3 +104,23 @@ def test_bf16_mfma_attention_close_to_fp32(n, d):
     for a, b in zip(outs[1], outs[0]):
         err = float((a - b).abs().max()) / float(b.abs().max())
         assert 0 < err < 3e-2, err
+
+
+def test_cross_attention_shapes_are_refused_not_misread():
+    """kanvit_attn_desc carries ONE sequence length: a shorter k/v would be read out of bounds and a longer one silently
+    truncated (the reference's FlashAttentionFunction accepts q_len != k_len, utils.py:150-160).  Both the module-level
+    function and the op-level binding must raise before anything is launched."""
+    from kanvit import ops
+    from kanvit._lib import KanvitError
+    from utils import FlashAttentionFunction
+    q = torch.randn(2, 2, 40, 32, device=DEV)
+    for nk in (24, 56):
+        k = torch.randn(2, 2, nk, 32, device=DEV)
+        with pytest.raises(NotImplementedError):
+            FlashAttentionFunction.apply(q, k, k, None, False, 512, 512)
+        with pytest.raises(KanvitError):
+            ops.attention(q, k, k)
+    with pytest.raises(KanvitError):                                    # head-size mismatch
+        ops.attention(q, torch.randn(2, 2, 40, 16, device=DEV), torch.randn(2, 2, 40, 16, device=DEV))
+    with pytest.raises(NotImplementedError):                            # key-padding masks: out of scope, loud
+        FlashAttentionFunction.apply(q, q, q, torch.ones(2, 40, dtype=torch.bool, device=DEV), False, 512, 512)
