@@ -213,6 +213,15 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
         int l31 = l31_, hf = hf_;
         asm volatile("" : "+s"(pw1), "+s"(pw2), "+s"(pb1), "+v"(l31), "+v"(hf));
         const long long m0 = (long long)tile * 32;
+        // the weight fragments of the first two products do not depend on the staged tiles: request them before the staging
+        // barrier so their L2 latency runs under it (they would otherwise queue up behind the barrier, one phase each)
+        float w1f[DH], w2f[DH];
+        ff_load_row<DH>(w1f, pw1 + (size_t)(nb + l31) * D + hf * DH);
+        {
+            const int voff = hf * DH * F + l31;
+#pragma unroll
+            for (int s = 0; s < DH; ++s) w2f[s] = (pw2 + (size_t)s * F + nb)[voff];
+        }
         // stage the x and dy tiles (rows past M: zero); LN: x is rebuilt from s and its row statistics
         for (int idx = tid; idx < 32 * (D / 4); idx += NT) {
             const int m = idx / (D / 4), c = idx % (D / 4);
@@ -242,11 +251,18 @@ __global__ __launch_bounds__(64 * NW) void ff_small_bwd_kernel(const FfArgs a) {
 #pragma unroll
         for (int t = 0; t < NTH; ++t) {
             const int n0 = nb + t * 32;
-            f32x16 h = ff_hidden_tile<D>(pw1, n0, l31, hf, xr);
-            // dh^T[n][m] = sum_o W2[o][n] dy[m][o]      (half h takes o = h*D/2 + s)
-            f32x16 dh = ff_zero16();
-            {       // addresses as a wave-uniform base (scalar registers) + ONE per-lane 32-bit offset: a 64-bit address per load
-                    // (the offsets do not fit the 12-bit immediate) costs two registers each and spills the kernel
+            f32x16 h, dh = ff_zero16();
+            // dh^T[n][m] = sum_o W2[o][n] dy[m][o]      (half h takes o = h*D/2 + s); addresses are a wave-uniform base (scalar
+            // registers) + ONE per-lane 32-bit offset: a 64-bit address per load (the offsets do not fit the 12-bit immediate)
+            // costs two registers each
+            if (t == 0) {
+                h = ff_zero16();
+#pragma unroll
+                for (int s = 0; s < DH; ++s) h = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[s], xr[s], h, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < DH; ++s) dh = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[s], dyr[s], dh, 0, 0, 0);
+            } else {
+                h = ff_hidden_tile<D>(pw1, n0, l31, hf, xr);
                 const int voff = hf * DH * F + l31;
 #pragma unroll
                 for (int s = 0; s < DH; ++s) {
