@@ -65,6 +65,7 @@ struct LayerArgs {
     // KANVIT_FLAG_FUSED_LN (RBF): the spline-path input u = LayerNorm(x slice) * gamma + beta (models/fastkan.py:68) is formed
     // in the kernels; bparams of a group = [centres(G) | gamma(I) | beta(I)]; stats[M][xmod][2] = (mean, rstd) per row and x
     // slice, written by the forward kernel and read by the two backward kernels
+    int vcols;            // bf16 input gradient of ONE wide layer (O = 64*v): the v column chunks run as "groups" sharing x, basis and chain rule
     int ln;
     float ln_eps;
     float* stats;
@@ -1515,8 +1516,11 @@ __global__ __launch_bounds__(KV_WS_THREADS, KV_WS_THREADS / 256) void kan_fwd_ws
 // Requirements: as the fp32 register kernel, plus O in {32, 64}.
 // =============================================================================================
 // wb2[g][nci][O/16][2][KCT][8]: element (ks, h, kr, e) = w[g][k(kr)][16*ks + 8*h + e], k(kr) by the slot permutation
+// (ldw, gstride): row stride of w and the offset between two "groups" -- (O, K*O) for real groups, (O_real, 64) when the groups
+// are the 64-column chunks of one wide layer
 __global__ __launch_bounds__(256) void kan_pack_w_bwd_reg_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb2,
-                                                                 int K, int O, int GP, int FPH, int KCT, int nci, long long total) {
+                                                                 int K, int O, int GP, int FPH, int KCT, int nci, long long total,
+                                                                 long long ldw, long long gstride) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (g, ci, ks, h, kr) per thread
     if (e >= total) return;
     const int kr = (int)(e % KCT);
@@ -1534,7 +1538,7 @@ __global__ __launch_bounds__(256) void kan_pack_w_bwd_reg_kernel(const float* __
     const int k = (ci * 2 * FPH + h_ * FPH + jq) * GP + g_;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (jq < FPH && k < K) ? w[(g * K + k) * O + 16 * ks + 8 * h + j] : 0.0f;
+    for (int j = 0; j < 8; ++j) v[j] = (jq < FPH && k < K) ? w[g * gstride + (long long)k * ldw + 16 * ks + 8 * h + j] : 0.0f;
     u32x4 out = {kv_pack_bf16(v[0], v[1]), kv_pack_bf16(v[2], v[3]), kv_pack_bf16(v[4], v[5]), kv_pack_bf16(v[6], v[7])};
     *reinterpret_cast<u32x4*>(wb2 + e * 8) = out;
 }
@@ -1648,7 +1652,7 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const La
             }
         const bool ends = SHARED ? (p == nshare - 1) : true;
         if (ends) {
-            const int g = p * a.xmod + gx;
+            const int g = a.vcols ? gx : p * a.xmod + gx;      // column chunks of one wide layer: ONE real group
             const BasisArgs b = make_basis(a, g);
             float duv[RBF ? FPH : 1];
             float uvv[RBF ? FPH : 1];
@@ -2886,7 +2890,8 @@ int bwd_input_ic(int I, int gp, int G, int nshare, int bf_O) {
 }
 
 bool bwd_input_bf16_ok(const kanvit_layer_desc* d) {
-    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64) && (d->ldy % 4 == 0) && !kv_config().no_bf16;
+    const bool wide = d->groups == 1 && d->x_group_mod == 1 && d->O > 64 && d->O % 64 == 0 && d->O <= 64 * 64;      // register kernel only
+    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64 || wide) && (d->ldy % 4 == 0) && !kv_config().no_bf16;
 }
 
 template <int FAM>
@@ -2947,6 +2952,7 @@ int try_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
 struct BwdRegBf16Plan {
     bool ok;
     int gp, kt, fph, nci;
+    int vcols;            // > 0: one wide layer (groups = 1, O = 64*vcols) contracted 64 columns at a time into the same accumulators
     size_t lds, ws_bytes;
 };
 
@@ -2962,10 +2968,13 @@ BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
     else return p;
     p.fph = 16 * p.kt / p.gp;
     const int ic = 2 * p.fph;
-    if (d->I % ic || !(d->O == 32 || d->O == 64)) return p;
+    const bool wide = d->groups == 1 && d->x_group_mod == 1 && d->O > 64 && d->O % 64 == 0 && d->O <= 64 * 64;
+    if (d->I % ic || !(d->O == 32 || d->O == 64 || wide)) return p;
     if ((d->ldx & 3) || (d->ldy & 3) || (d->I & 3) || (fam == KANVIT_RBF && (d->ldu & 3))) return p;
     p.nci = d->I / ic;
-    p.lds = (size_t)2 * (d->O / 16) * 2 * 32 * p.kt * 16;
+    p.vcols = wide ? d->O / 64 : 0;
+    const int oc = wide ? 64 : d->O;                 // columns per step
+    p.lds = (size_t)2 * (oc / 16) * 2 * 32 * p.kt * 16;
     p.ws_bytes = (size_t)d->groups * p.nci * (d->O / 16) * 2 * 32 * p.kt * 16;
     p.ok = true;
     return p;
@@ -2974,8 +2983,24 @@ BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
 template <int FAM, int GP, int KT>
 int launch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t st) {
     const long long total = (long long)a.groups * p.nci * (a.O / 16) * 2 * 32 * KT;
+    if (p.vcols) {
+        // one wide layer (the patch embedding: O = 384 / 768): its 64-column chunks are contracted one per step into the SAME
+        // accumulators -- exactly the SHARED schedule with the chunks in the role of the groups that share x and the basis
+        hipLaunchKernelGGL(kan_pack_w_bwd_reg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w,
+                           const_cast<unsigned short*>(a.wb2), a.K, 64, GP, p.fph, 32 * KT, p.nci, total, (long long)a.O, 64LL);
+        KV_LAUNCH_CHECK("kan_pack_w_bwd_reg_kernel");
+        LayerArgs v = a;
+        v.groups = p.vcols;
+        v.xmod = 1;
+        v.O = 64;
+        v.vcols = 1;
+        dim3 vgrid(1, (unsigned)((a.M + BM - 1) / BM), 1);
+        hipLaunchKernelGGL((kan_bwd_input_reg_bf16_kernel<FAM, GP, KT, true>), vgrid, dim3(256), p.lds, st, v);
+        KV_LAUNCH_CHECK("kan_bwd_input_reg_bf16_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(kan_pack_w_bwd_reg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w,
-                       const_cast<unsigned short*>(a.wb2), a.K, a.O, GP, p.fph, 32 * KT, p.nci, total);
+                       const_cast<unsigned short*>(a.wb2), a.K, a.O, GP, p.fph, 32 * KT, p.nci, total, (long long)a.O, (long long)a.K * a.O);
     KV_LAUNCH_CHECK("kan_pack_w_bwd_reg_kernel");
     const int nshare = a.groups / a.xmod;
     const bool shared = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare > 1;
@@ -3464,7 +3489,7 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
             KV_FAMILY_SWITCH(d->family, KV_CALL)
 #undef KV_CALL
         }
-        if (a.ln) a.wb2 = nullptr;     // no LayerNorm fusion in the LDS-tile bf16 kernel: the exact register kernel runs instead
+        if (a.ln || d->O > 64) a.wb2 = nullptr;     // no LayerNorm fusion / no wide layers in the LDS-tile bf16 kernel: the exact register kernel runs instead
     }
 #define KV_CALL(F) dispatch_bwd_input<F>(a, st)
     KV_FAMILY_SWITCH(d->family, KV_CALL)
