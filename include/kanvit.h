@@ -44,7 +44,11 @@ extern "C" {
 #define KANVIT_FLAG_UNIFORM_KNOTS 2 /* BSPLINE, spline_order 3: every knot row is g0 + j*h (the layout the reference builds
                                     at models/effkan.py:44-53 and never changes) -> closed-form cubic evaluation of
                                     the 4 non-zero bases instead of the Cox-de Boor recursion.  g0, h are read from
-                                    the first two knots of each group.                                              */
+                                    the first two knots of each group.
+                                    RBF with G = 8: the centres are c0 + j/rbf_inv_h (FastKAN's own grid, models/
+                                    fastkan.py:22-27: linspace centres, denominator = their spacing) -> the eight
+                                    Gaussians come from two exp anchors and a two-step recurrence instead of eight
+                                    exps (relative error <= ~2e-6); the caller vouches for the layout.             */
 #define KANVIT_FLAG_FUSED_LN 8   /* RBF (FastKAN): the LayerNorm in front of the spline path (models/fastkan.py:68) is formed IN the
                                     kernels: u = (x - mean) * rstd * gamma + beta over the I features of the group's x slice,
                                     eps = ln_eps.  bparams of a group = [centres(G) | gamma(I) | beta(I)].  The `u` argument

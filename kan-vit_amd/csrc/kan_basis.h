@@ -41,6 +41,44 @@ __device__ __forceinline__ float kv_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
+// FastKAN's own grid (models/fastkan.py:22-27: G = 8 centres linspace(min, max), denominator = their spacing h): with
+// t = (u - c0)/h the basis is exp(-(t - j)^2) and phi_{j+1} = phi_j * exp(2t - 1) * exp(-2j).  Two anchors (j = 2 and 5) by
+// exp, every other value at most two steps away: 3 v_exp + 1 v_rcp + 12 v_mul for the eight values instead of eight times
+// (sub, mul, mul, mul, exp) -- the RBF kernels are bound by this VALU work, not by the matrix pipe.
+// Error: two steps x ~2 ulp (the ratio exp(2t - 1) is formed with a compensated argument, kv_exp_comp) ~ 5e-7 relative.  An anchor that
+// underflows (|t - 2| or |t - 5| > 9.3) zeroes values whose true size is < 3e-30; t is clamped so exp(2t - 1) stays finite
+// (everything is 0 out there); the compare form of the clamp lets a NaN input stay a NaN.
+// exp(x) with the rounding of x*log2(e) compensated (the fast __expf loses |x| * 6e-8 relative there: 8e-7 at x = 13, and the
+// recurrence below multiplies by this value up to twice); v_exp_f32's own ~1 ulp remains
+__device__ __forceinline__ float kv_exp_comp(float x) {
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500e-8f;
+    const float y = x * L2E;
+    const float lo = __builtin_fmaf(x, L2E, -y) + x * L2E_LO;
+    const float e = __builtin_amdgcn_exp2f(y);
+    return __builtin_fmaf(e, lo * 0.69314718f, e);
+}
+__device__ __forceinline__ void kv_rbf8(float t, float (&p)[8]) {
+    const float tc = t < -20.0f ? -20.0f : (t > 30.0f ? 30.0f : t);
+    const float a2 = tc - 2.0f, a5 = tc - 5.0f;
+    const float e2 = __expf(-a2 * a2), e5 = __expf(-a5 * a5);
+    const float R = kv_exp_comp(2.0f * tc - 1.0f);
+    const float Ri = __builtin_amdgcn_rcpf(R);
+    p[2] = e2;
+    p[3] = e2 * (R * 1.8315639e-02f);        // exp(-4)
+    p[1] = e2 * (Ri * 7.3890561f);           // exp(2)
+    p[0] = p[1] * Ri;
+    p[5] = e5;
+    p[6] = e5 * (R * 4.5399930e-05f);        // exp(-10)
+    p[7] = p[6] * (R * 6.1442124e-06f);      // exp(-12)
+    p[4] = e5 * (Ri * 2.9809580e+03f);       // exp(8)
+}
+// p[j] without a runtime-indexed register array (which would live in scratch): folds to one register when j is a constant
+__device__ __forceinline__ float kv_sel8(const float (&p)[8], int j) {
+    const float a = (j & 1) ? p[1] : p[0], b = (j & 1) ? p[3] : p[2], c = (j & 1) ? p[5] : p[4], d = (j & 1) ? p[7] : p[6];
+    const float ab = (j & 2) ? b : a, cd = (j & 2) ? d : c;
+    return (j & 4) ? cd : ab;
+}
+
 // sin and cos together, |x| up to ~5e4 with <= 9e-8 absolute error (libm's float sin: 7e-8): k = rint(x * 2/pi), a
 // three-term Cody-Waite reduction r = x - k*pi/2 (exact products through fma), then the Cephes minimax polynomials on
 // [-pi/4, pi/4] and a quadrant swap.  ~20 VALU ops for both values; ocml's sinf + cosf (Payne-Hanek path included) are
@@ -335,13 +373,14 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
 // ---------------------------------------------------------------------------------------------
 template <int FAM, int GP>
 struct BasisGenP {
-    static constexpr int NC0 = (FAM == KV_SINE || FAM == KV_RBF) ? GP : 1;
+    static constexpr int NC0 = (FAM == KV_SINE) ? GP : 1;         // RBF: only the first centre (uniform grid, kv_rbf8)
     static constexpr int NC1 = (FAM == KV_SINE) ? GP : 1;
     float c0[NC0], c1[NC1];
     float g0, ih, inv_h;
     int nkm1, G;
     float x, u, t, p0, p1;
     float bv[4];
+    float pr[(FAM == KV_RBF) ? 8 : 1];      // RBF (uniform grid, host-checked): the eight values of this token (kv_rbf8)
     int j0;
     bool in;
 
@@ -362,9 +401,8 @@ struct BasisGenP {
             }
         } else if constexpr (FAM == KV_FOURIER) {       // window lies inside the cos block (j0 < G) or the sin block
             sin_half = j0 >= b.G;
-        } else if constexpr (FAM == KV_RBF) {
-#pragma unroll
-            for (int j = 0; j < GP; ++j) c0[j] = (j0 + j < b.G) ? b.bp[j0 + j] : 0.0f;
+        } else if constexpr (FAM == KV_RBF) {               // uniform 8-centre grid and j0 == 0 (host-checked: the register kernels' only RBF layout)
+            c0[0] = b.bp[0];
         } else if constexpr (FAM == KV_BSPLINE) {       // uniform knots (host-checked)
             g0 = b.bp[0];
             nkm1 = b.nk - 1;
@@ -374,6 +412,7 @@ struct BasisGenP {
     __device__ __forceinline__ void init(float xv, float uv) {
         x = xv;
         u = uv;
+        if constexpr (FAM == KV_RBF) kv_rbf8((uv - c0[0]) * inv_h, pr);
         if constexpr (FAM == KV_CHEBY) {
             t = kv_tanh(xv);
             p0 = 1.0f;
@@ -413,8 +452,7 @@ struct BasisGenP {
             return (in && e >= 0 && e < 4) ? v : 0.0f;
         } else if constexpr (FAM == KV_RBF) {
             if (j0w + j >= G) return kv_silu(x);
-            const float d = (u - c0[j < NC0 ? j : 0]) * inv_h;
-            return __expf(-d * d);
+            return kv_sel8(pr, j);
         } else if constexpr (FAM == KV_FOURIER) {
             const float v = sin_half ? sk : ck;
             const float cn = ck * c1r - sk * s1;
@@ -456,6 +494,7 @@ __device__ __forceinline__ void basis_bwd_sine_reg(const BasisArgs& b, float xv,
 template <int FAM>
 struct BasisGen {
     float x, u, t, p0, p1, c1, s1, ck, sk;
+    float pr[(FAM == KV_RBF) ? 8 : 1];      // RBF (uniform grid, host-checked): kv_rbf8
     float bv[4];
     int j0, G, i;
     bool in;
@@ -471,6 +510,7 @@ struct BasisGen {
         bp = b.bp;
         inv_h = b.inv_h;
         has_base = b.has_base;
+        if constexpr (FAM == KV_RBF) kv_rbf8((uv - b.bp[0]) * b.inv_h, pr);
         if constexpr (FAM == KV_CHEBY) {
             t = kv_tanh(xv);
             p0 = 1.0f;
@@ -501,8 +541,7 @@ struct BasisGen {
             return (in && e >= 0 && e < 4) ? v : 0.0f;
         } else if constexpr (FAM == KV_RBF) {
             if (j >= G) return kv_silu(x);
-            const float d = (u - bp[j]) * inv_h;
-            return __expf(-d * d);
+            return kv_sel8(pr, j);
         } else if constexpr (FAM == KV_SINE) {
             return kv_sin(__fadd_rn(__fmul_rn(x, bp[j]), bp[G + (long long)i * G + j]));
         } else {   // FOURIER: cos(k x) for j < G, then sin(k x)
@@ -525,6 +564,7 @@ struct BasisGen {
 template <int FAM>
 struct BasisDGen {
     float x, u, t, sech2, u0, u1, c1, s1, ck, sk, inv_h;
+    float pr[(FAM == KV_RBF) ? 8 : 1];
     float lastc;   // SINE: cos(x f_j + p_ij) of the last next() (the caller needs it for d loss / d freq)
     float dv[4];
     int j0, G, i;
@@ -538,6 +578,10 @@ struct BasisDGen {
         G = b.G;
         bp = b.bp;
         inv_h = b.inv_h;
+        if constexpr (FAM == KV_RBF) {
+            t = (uv - b.bp[0]) * b.inv_h;
+            kv_rbf8(t, pr);
+        }
         if constexpr (FAM == KV_CHEBY) {
             t = kv_tanh(xv);
             sech2 = 1.0f - t * t;
@@ -570,8 +614,7 @@ struct BasisDGen {
             return (in && e >= 0 && e < 4) ? v : 0.0f;
         } else if constexpr (FAM == KV_RBF) {
             if (j >= G) return kv_dsilu(x);
-            const float d = (u - bp[j]) * inv_h;
-            return __expf(-d * d) * (-2.0f * d * inv_h);
+            return kv_sel8(pr, j) * (-2.0f * (t - (float)j) * inv_h);
         } else if constexpr (FAM == KV_SINE) {      // d sin(x f + p)/dx = f cos(x f + p)
             const float f = bp[j];
             lastc = kv_cos(__fadd_rn(__fmul_rn(x, f), bp[G + (long long)i * G + j]));

@@ -2547,6 +2547,10 @@ LayerArgs base_args(const kanvit_layer_desc* d) {
 int needs_bparams(int family) { return family == KANVIT_BSPLINE || family == KANVIT_RBF || family == KANVIT_SINE; }
 
 // ---- forward -----------------------------------------------------------------------------------
+// RBF in the register kernels: only FastKAN's own uniform 8-centre grid (kv_rbf8: two exp anchors + recurrence); the caller
+// vouches with KANVIT_FLAG_UNIFORM_KNOTS, anything else takes the LDS-tile kernels (direct exp per centre)
+inline bool kv_rbf_reg_ok(int flags, int G) { return (flags & KANVIT_FLAG_UNIFORM_KNOTS) && G == 8; }
+
 // families that get shared-basis (NSH = 3 / SHARED) kernel instantiations ...
 template <int FAM>
 constexpr bool kv_shared_basis() { return FAM == KV_LINEAR || FAM == KV_CHEBY || FAM == KV_FOURIER || FAM == KV_BSPLINE; }
@@ -2596,7 +2600,7 @@ FwdRegBf16Plan plan_fwd_reg_bf16(const kanvit_layer_desc* d) {
     const int fam = d->family;
     const bool gp_ok = (fam == KANVIT_LINEAR && p.gp == 1) || (fam == KANVIT_CHEBY && p.gp == 5) ||
                        (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) ||
-                       (fam == KANVIT_RBF && p.gp == 9) || (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 28)) ||
+                       (fam == KANVIT_RBF && p.gp == 9 && kv_rbf_reg_ok(d->flags, d->G)) || (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 28)) ||
                        (fam == KANVIT_FOURIER && p.gp == 56);
     if (!gp_ok) return p;
     p.nt = d->O <= 32 ? 1 : (d->O <= 64 ? 2 : 4);
@@ -2775,6 +2779,7 @@ template <int FAM>
 int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
     if (kv_config().no_reg) return 1;
     if (FAM == KV_BSPLINE && !((a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3)) return 1;
+    if (FAM == KV_RBF && !kv_rbf_reg_ok(a.flags, a.G)) return 1;
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     if (a.O % (32 * nt)) return 1;
     const int nshare = a.groups / a.xmod;
@@ -2938,7 +2943,7 @@ int try_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
     if constexpr (FAM == KV_BSPLINE) {
         if (a.GP == 9 && (a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3) return launch_bwd_input_reg<FAM, 9, 5>(a, st);
     }
-    if constexpr (FAM == KV_RBF) { if (a.GP == 9 && a.has_base) return launch_bwd_input_reg<FAM, 9, 5>(a, st); }
+    if constexpr (FAM == KV_RBF) { if (a.GP == 9 && a.has_base && kv_rbf_reg_ok(a.flags, a.G)) return launch_bwd_input_reg<FAM, 9, 5>(a, st); }
     if constexpr (FAM == KV_FOURIER) { if (a.GP == 56) return launch_bwd_input_reg<FAM, 56, 7>(a, st); }
     if constexpr (FAM == KV_SINE) {   // attention.py:140 builds the per-head sine mappings with grid_size = 4; 5 is the layer's default
         if (a.GP == 4) return launch_bwd_input_reg<FAM, 4, 4>(a, st);
@@ -2964,7 +2969,7 @@ BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
     if (fam == KANVIT_LINEAR && p.gp == 1) p.kt = 2;
     else if (fam == KANVIT_CHEBY && p.gp == 5) p.kt = 5;
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) p.kt = 5;
-    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.kt = 5;
+    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.kt = 5;
     else return p;
     p.fph = 16 * p.kt / p.gp;
     const int ic = 2 * p.fph;
@@ -3140,7 +3145,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // it loses to the LDS-tile kernel (2.46 vs 1.15 ms on the ViT-B q|k|v launch) -- opt-in only until that is fixed
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 &&
              kv_config().reg_bw_bspline) p.nt = 2;
-    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
+    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
     else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }          // windows of 4 basis functions
     else if (fam == KANVIT_FOURIER && p.gp == 56) { p.nt = 4; p.njc = 14; }
@@ -3341,7 +3346,7 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
 
 /* 1 when the three register kernels that can form the FastKAN LayerNorm in-kernel cover this layer (pure host function) */
 int kanvit_layer_ln_fusable(const kanvit_layer_desc* d) {
-    if (!d || d->family != KANVIT_RBF || !d->has_base || d->G != 8 || d->groups < 1 || d->x_group_mod < 1) return 0;
+    if (!d || d->family != KANVIT_RBF || !d->has_base || !kv_rbf_reg_ok(d->flags, d->G) || d->groups < 1 || d->x_group_mod < 1) return 0;
     if (d->I % 32 || d->O % 32 || d->M < 256 || (d->ldx & 3) || (d->ldy & 3)) return 0;
     if (d->O > 64 && d->O % 128) return 0;                 // forward column tiling: 32, 64 or multiples of 128
     {                                                      // kanvit_layer_ln_bwd's lane-group layout

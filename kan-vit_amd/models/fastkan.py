@@ -9,6 +9,31 @@ import torch.nn.functional as F
 from kanvit import grouped, ops
 
 
+_RBF_FACTS = {}
+
+
+def _rbf_grid_is_default(layers) -> bool:
+    """True when every layer's centres are c0 + j*h with h = the layer's denominator and num_grids = 8 -- the grid
+    models/fastkan.py:22-27 builds -- and all layers agree.  Then the kernels may use the two-anchor recurrence
+    (KANVIT_FLAG_UNIFORM_KNOTS).  Checked once per set of grid buffers (one host sync), cached on their version counters."""
+    key = tuple((id(m), m.rbf.grid._version, m.rbf.grid.data_ptr(), float(m.rbf.denominator)) for m in layers)
+    hit = _RBF_FACTS.get(key)
+    if hit is None:
+        l0 = layers[0]
+        g = l0.rbf.grid.detach().double()
+        h = float(l0.rbf.denominator)
+        ok = g.numel() == 8 and h > 0
+        if ok:
+            ideal = g[0] + h * torch.arange(8, device=g.device, dtype=torch.float64)
+            ok = float((g - ideal).abs().max()) <= 2e-6 * (float(g.abs().max()) + 1.0)
+        ok = ok and all(float(m.rbf.denominator) == h and m.rbf.grid.shape == l0.rbf.grid.shape and bool((m.rbf.grid == l0.rbf.grid).all())
+                        for m in layers[1:])
+        if len(_RBF_FACTS) > 256:
+            _RBF_FACTS.clear()
+        hit = _RBF_FACTS[key] = bool(ok)
+    return hit
+
+
 class SplineLinear(nn.Linear):
     """Bias-free linear whose weight starts as trunc_normal(0, init_scale) (models/fastkan.py:6-12)."""
 
@@ -58,9 +83,12 @@ class FastKANLayer(nn.Module):
             self.base_activation = base_activation
             self.base_linear = nn.Linear(input_dim, output_dim)
 
-    def kan_cfg(self):
+    def kan_cfg(self, layers=None):
+        from kanvit import _lib
+        uni = _rbf_grid_is_default(layers if layers is not None else [self])
         return ops.LayerCfg(family=ops.RBF, I=self.input_dim, O=self.output_dim, G=self.num_grids,
-                            has_base=int(self.use_base_update), rbf_inv_h=1.0 / float(self.rbf.denominator))
+                            has_base=int(self.use_base_update), rbf_inv_h=1.0 / float(self.rbf.denominator),
+                            flags=_lib.FLAG_UNIFORM_KNOTS if uni else 0)
 
     def kan_pack(self):
         i, g, o = self.input_dim, self.num_grids, self.output_dim

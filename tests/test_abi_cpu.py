@@ -53,7 +53,7 @@ def test_fused_layernorm_query_is_host_only(lib):
 
     def desc(**kw):
         base = dict(family=_lib.RBF, groups=18, x_group_mod=6, I=64, O=64, G=8, has_base=1, rbf_inv_h=1.75, M=25216,
-                    ldx=384, ldu=1152, ldy=1152, bparam_stride=8 + 128, ln_eps=1e-5)
+                    ldx=384, ldu=1152, ldy=1152, bparam_stride=8 + 128, ln_eps=1e-5, flags=_lib.FLAG_UNIFORM_KNOTS)
         base.update(kw)
         return _lib.LayerDesc(**base)
 
@@ -63,14 +63,15 @@ def test_fused_layernorm_query_is_host_only(lib):
     assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(M=100))) == 0                    # too few rows for the register kernels
     assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(I=50, ldx=300))) == 0            # ragged feature count
     assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(has_base=0))) == 0
+    assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(flags=0))) == 0                  # centres not vouched uniform: LDS-tile kernels, no fusion
     assert lib.kanvit_layer_ln_fusable(ctypes.byref(desc(family=_lib.CHEBY, G=5))) == 0
     d = desc(family=_lib.CHEBY, G=5, flags=_lib.FLAG_FUSED_LN)
     assert lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -22
     assert b"FUSED_LN" in lib.kanvit_last_error()
-    d = desc(flags=_lib.FLAG_FUSED_LN, bparam_stride=8)
+    d = desc(flags=_lib.FLAG_FUSED_LN | _lib.FLAG_UNIFORM_KNOTS, bparam_stride=8)
     assert lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == -22
     assert b"gamma" in lib.kanvit_last_error()
-    d = desc(flags=_lib.FLAG_FUSED_LN, M=100)
+    d = desc(flags=_lib.FLAG_FUSED_LN | _lib.FLAG_UNIFORM_KNOTS, M=100)
     assert lib.kanvit_layer_bwd_weight(ctypes.byref(d), None, None, None, None, None, None, 0, None) == -22
 
 

@@ -89,7 +89,8 @@ def test_grouped_qkv_fused_equals_unfused(geom, monkeypatch):
         (y * w).sum().backward()
         return y.detach(), xg.grad, {k: v.grad.clone() for k, v in msa.named_parameters() if v.grad is not None}
 
-    cfg = ops.LayerCfg(family=ops.RBF, I=d // h, O=d // h, G=8, groups=3 * h, x_group_mod=h, has_base=1, rbf_inv_h=1.75)
+    cfg = ops.LayerCfg(family=ops.RBF, I=d // h, O=d // h, G=8, groups=3 * h, x_group_mod=h, has_base=1, rbf_inv_h=1.75,
+                       flags=_lib.FLAG_UNIFORM_KNOTS)
     assert ops.ln_fusable(cfg, b * n)
     y1, gx1, gp1 = run()
     monkeypatch.setenv("KANVIT_NO_FUSED_LN", "1")
@@ -201,10 +202,37 @@ def test_flag_misuse_is_refused():
     bp = torch.zeros(1, 8 + 128, device=DEV)
     y = torch.empty(512, 64, device=DEV)
     d = _lib.LayerDesc(family=_lib.RBF, groups=1, x_group_mod=1, I=64, O=64, G=8, has_base=1, rbf_inv_h=1.75,
-                       flags=_lib.FLAG_FUSED_LN, M=512, ldx=64, ldu=64, ldy=64, bparam_stride=136, ln_eps=1e-5)
+                       flags=_lib.FLAG_FUSED_LN | _lib.FLAG_UNIFORM_KNOTS, M=512, ldx=64, ldu=64, ldy=64, bparam_stride=136, ln_eps=1e-5)
     p = lambda t: C.c_void_p(t.data_ptr())
     rc = L.kanvit_layer_fwd(C.byref(d), p(x), None, p(w), p(bp), None, p(y), None, 0, None)      # no statistics buffer
     assert rc == -22 and b"statistics" in L.kanvit_last_error()
     pd = _lib.PatchDesc(1, 64, 64, 8, 1, 0)
     rc = L.kanvit_patch_embed_fwd(C.byref(d), C.byref(pd), p(x), p(w), p(bp), None, p(y), p(y), p(y), None)
     assert rc == -22
+
+
+def test_non_default_rbf_grid_takes_the_general_kernels():
+    """The register kernels evaluate the eight Gaussians by a recurrence that assumes FastKAN's own grid (centres c0 + j*h, h =
+    denominator).  A layer built with another denominator must not be vouched uniform: it runs the LDS-tile kernels (direct
+    exp per centre, separate LayerNorm) and still matches the oracle."""
+    from kanvit import _lib, ops
+    from models.fastkan import FastKANLayer
+    torch.manual_seed(12)
+    layer = FastKANLayer(64, 64)
+    layer.rbf.denominator = 0.9                       # spacing is 4/7: no longer the default layout
+    x = torch.randn(300, 64)
+    w = torch.randn(300, 64)
+    sd = {k: v.detach().double() for k, v in layer.state_dict().items()}
+    xd = x.double().requires_grad_(True)
+    want = ko.fastkan_forward(xd, sd["layernorm.weight"], sd["layernorm.bias"], sd["rbf.grid"], sd["spline_linear.weight"],
+                              sd["base_linear.weight"], sd["base_linear.bias"], denominator=0.9)
+    (want * w.double()).sum().backward()
+    layer = layer.to(DEV)
+    assert not (layer.kan_cfg().flags & _lib.FLAG_UNIFORM_KNOTS) and not ops.ln_fusable(layer.kan_cfg(), 300)
+    xg = x.to(DEV).requires_grad_(True)
+    y = layer(xg)
+    (y * w.to(DEV)).sum().backward()
+    assert max_err(y.cpu(), want) < 2e-5 * max(1.0, float(want.abs().max()))
+    assert rel_err(xg.grad.cpu(), xd.grad) < TOL
+    default = FastKANLayer(64, 64).to(DEV)
+    assert default.kan_cfg().flags & _lib.FLAG_UNIFORM_KNOTS and ops.ln_fusable(default.kan_cfg(), 300)

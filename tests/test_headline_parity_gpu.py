@@ -37,8 +37,9 @@ def test_msa_headline_geometry_against_reference(t):
     assert set(want) == set(got)
     for k, g in want.items():
         # key-bias gradients are mathematically zero (softmax shift invariance); the reference's own value is rounding noise
-        # of a few 1e-6 at this loss scale, and so is ours: the absolute term covers them and nothing else
-        assert close(got[k], g, rtol=TOL, atol=1e-5), (k, rel_err(got[k], g))
+        # of a few 1e-6 at this loss scale (the other gradients of these layers are O(1..10)), and so is ours (up to 9e-6
+        # observed, a different noise realisation per kernel revision): the absolute term covers them and nothing else
+        assert close(got[k], g, rtol=TOL, atol=2e-5), (k, rel_err(got[k], g))
 
 
 def _oracle_qkv(msa, x2d, w, h):

@@ -249,7 +249,10 @@ def test_weight_gradient_kernels_agree_and_are_deterministic(fam, amp, monkeypat
         _lib.reload_config()
     assert all(torch.equal(reg[0], r) for r in reg[1:])
     assert torch.equal(tile[0], tile[1])
-    assert float((reg[0] - tile[0]).abs().max()) / float(tile[0].abs().max()) < 1e-5
+    # FastKAN: the register kernel forms the eight Gaussians by the two-anchor recurrence, the LDS-tile kernel by one exp per
+    # centre (relative difference <= ~2e-6 in fp32); under bf16 such a difference flips roundings of single basis values
+    tol = 2e-3 if (fam == "fast" and amp) else 1e-5
+    assert float((reg[0] - tile[0]).abs().max()) / float(tile[0].abs().max()) < tol
 
 
 def test_bspline_non_uniform_or_differing_grids_take_the_general_path():
