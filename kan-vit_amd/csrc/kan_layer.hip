@@ -2896,6 +2896,9 @@ int bwd_input_ic(int I, int gp, int G, int nshare, int bf_O) {
 
 bool bwd_input_bf16_ok(const kanvit_layer_desc* d) {
     const bool wide = d->groups == 1 && d->x_group_mod == 1 && d->O > 64 && d->O % 64 == 0 && d->O <= 64 * 64;      // register kernel only
+    // SINE has no bf16 register kernel (its d loss / d freq partials), and the bf16 LDS-tile kernel measures SLOWER than the exact
+    // fp32 register kernel (0.81 vs 0.38 ms on the ViT-B q|k|v launch): the flag allows bf16, it does not require it
+    if (d->family == KANVIT_SINE && !kv_config().no_reg) return false;
     return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64 || wide) && (d->ldy % 4 == 0) && !kv_config().no_bf16;
 }
 
