@@ -1544,12 +1544,13 @@ __global__ __launch_bounds__(256) void kan_pack_w_bwd_reg_kernel(const float* __
 }
 
 template <int FAM, int GP, int KT, bool SHARED>
-__global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const LayerArgs a) {
+__global__ __launch_bounds__(256, FAM == KV_SINE ? 1 : 2) void kan_bwd_input_reg_bf16_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KCT = 32 * KT;
     constexpr int FPH = (16 * KT) / GP;
     constexpr int IC = 2 * FPH;
     constexpr bool RBF = (FAM == KV_RBF);
+    constexpr bool SINE = (FAM == KV_SINE);
     constexpr int MAXKS = 4;                      // O <= 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int gx = blockIdx.x;
@@ -1563,6 +1564,12 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const La
     unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [2][nks][2][KCT][8]
     const int WSZ = nks * 2 * KCT * 8;            // bf16 elements per buffer
     const int NV = nks * 2 * KCT;                 // 16-byte vectors per buffer
+    // SINE: [real groups sharing x][4 waves][GP] partial d loss / d freq of this row tile (as the fp32 register kernel)
+    const int ndf = a.vcols ? 1 : nshare;
+    float* dfq_s = reinterpret_cast<float*>(W_s + 2 * (size_t)WSZ);
+    if constexpr (SINE) {
+        for (int j = tid; j < ndf * 4 * GP; j += 256) dfq_s[j] = 0.0f;
+    }
 
     const float* xrow = a.x + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     float* dxrow = a.dx + grow * a.ldx + (long long)gx * a.I + hf * FPH;
@@ -1668,6 +1675,11 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const La
                     for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
                 }
             }
+            float dfq[SINE ? GP : 1];
+            if constexpr (SINE) {
+#pragma unroll
+                for (int g_ = 0; g_ < GP; ++g_) dfq[g_] = 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < FPH; ++j) {
                 BasisDGen<FAM> gen;
@@ -1680,9 +1692,18 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const La
                     const float v = acc[slot / 16][slot % 16];
                     if (RBF && g_ < GP - 1) usum += v * d;
                     else dsum += v * d;
+                    if constexpr (SINE) dfq[g_] += v * gen.lastc * xv[j];
                 }
                 dxacc[j] += dsum;
                 if constexpr (RBF) duv[j] = usum;
+            }
+            if constexpr (SINE) {                 // one wave reduction per grid point and step; rows past M contribute nothing
+                const int pg = a.vcols ? 0 : p;
+#pragma unroll
+                for (int g_ = 0; g_ < GP; ++g_) {
+                    const float part = kv_wave_sum(row_ok ? dfq[g_] : 0.0f);
+                    if (lane == 0) dfq_s[(pg * 4 + wave) * GP + g_] += part;
+                }
             }
             if constexpr (RBF) {
                 if (a.du && row_ok) {
@@ -1713,6 +1734,15 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_reg_bf16_kernel(const La
         if (t + 1 < T) store_w((t + 1) & 1);
         __syncthreads();
         ci = cin; p = pn;
+    }
+    if constexpr (SINE) {                         // combine the 4 waves in a fixed order (the last loop barrier orders the adds)
+        const int rgroups = a.vcols ? 1 : a.groups;
+        for (int j = tid; j < ndf * GP; j += 256) {
+            const int pp = j / GP, gg = j - pp * GP;
+            const float* src = dfq_s + (pp * 4) * GP + gg;
+            const float v = ((src[0] + src[GP]) + src[2 * GP]) + src[3 * GP];
+            a.dparam[((long long)blockIdx.y * rgroups + (a.vcols ? 0 : pp * a.xmod + gx)) * a.G + gg] = v;
+        }
     }
 }
 
@@ -2894,13 +2924,7 @@ int bwd_input_ic(int I, int gp, int G, int nshare, int bf_O) {
     return bwd_input_lds<FAM>(ic, gp, G, nshare, bf_O) > 160 * 1024 ? 0 : ic;
 }
 
-bool bwd_input_bf16_ok(const kanvit_layer_desc* d) {
-    const bool wide = d->groups == 1 && d->x_group_mod == 1 && d->O > 64 && d->O % 64 == 0 && d->O <= 64 * 64;      // register kernel only
-    // SINE has no bf16 register kernel (its d loss / d freq partials), and the bf16 LDS-tile kernel measures SLOWER than the exact
-    // fp32 register kernel (0.81 vs 0.38 ms on the ViT-B q|k|v launch): the flag allows bf16, it does not require it
-    if (d->family == KANVIT_SINE && !kv_config().no_reg) return false;
-    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64 || wide) && (d->ldy % 4 == 0) && !kv_config().no_bf16;
-}
+bool bwd_input_bf16_ok(const kanvit_layer_desc* d);
 
 template <int FAM>
 size_t bwd_input_ws(const kanvit_layer_desc* d) {
@@ -2973,6 +2997,8 @@ BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
     else if (fam == KANVIT_CHEBY && p.gp == 5) p.kt = 5;
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) p.kt = 5;
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.kt = 5;
+    else if (fam == KANVIT_SINE && p.gp == 4) p.kt = 4;        // the per-head mappings (attention.py:140)
+    else if (fam == KANVIT_SINE && p.gp == 28) p.kt = 7;       // the G = 28 patch embedding (model.py:72)
     else return p;
     p.fph = 16 * p.kt / p.gp;
     const int ic = 2 * p.fph;
@@ -2983,9 +3009,18 @@ BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
     p.vcols = wide ? d->O / 64 : 0;
     const int oc = wide ? 64 : d->O;                 // columns per step
     p.lds = (size_t)2 * (oc / 16) * 2 * 32 * p.kt * 16;
+    if (fam == KANVIT_SINE) p.lds += sizeof(float) * (size_t)(wide ? 1 : d->groups / d->x_group_mod) * 4 * p.gp;
     p.ws_bytes = (size_t)d->groups * p.nci * (d->O / 16) * 2 * 32 * p.kt * 16;
     p.ok = true;
     return p;
+}
+
+bool bwd_input_bf16_ok(const kanvit_layer_desc* d) {
+    const bool wide = d->groups == 1 && d->x_group_mod == 1 && d->O > 64 && d->O % 64 == 0 && d->O <= 64 * 64;      // register kernel only
+    // SINE has no bf16 register kernel (its d loss / d freq partials), and the bf16 LDS-tile kernel measures SLOWER than the exact
+    // fp32 register kernel (0.81 vs 0.38 ms on the ViT-B q|k|v launch): the flag allows bf16, it does not require it
+    if (d->family == KANVIT_SINE && !kv_config().no_reg && !plan_bwd_input_reg_bf16(d).ok) return false;
+    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64 || wide) && (d->ldy % 4 == 0) && !kv_config().no_bf16;
 }
 
 template <int FAM, int GP, int KT>
@@ -3031,6 +3066,10 @@ int dispatch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream
     if constexpr (FAM == KV_CHEBY) return launch_bwd_input_reg_bf16<FAM, 5, 5>(a, p, st);
     if constexpr (FAM == KV_BSPLINE) return launch_bwd_input_reg_bf16<FAM, 9, 5>(a, p, st);
     if constexpr (FAM == KV_RBF) return launch_bwd_input_reg_bf16<FAM, 9, 5>(a, p, st);
+    if constexpr (FAM == KV_SINE) {
+        if (!a.dparam) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: SINE needs dparam");
+        return p.gp == 28 ? launch_bwd_input_reg_bf16<FAM, 28, 7>(a, p, st) : launch_bwd_input_reg_bf16<FAM, 4, 4>(a, p, st);
+    }
     return kv_fail(KANVIT_EINVAL, "internal: bf16 register input-gradient dispatch");
 }
 
@@ -3497,7 +3536,7 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
             KV_FAMILY_SWITCH(d->family, KV_CALL)
 #undef KV_CALL
         }
-        if (a.ln || d->O > 64) a.wb2 = nullptr;     // no LayerNorm fusion / no wide layers in the LDS-tile bf16 kernel: the exact register kernel runs instead
+        if (a.ln || d->O > 64 || d->family == KANVIT_SINE) a.wb2 = nullptr;     // no LayerNorm fusion / no wide layers in the LDS-tile bf16 kernel: the exact register kernel runs instead
     }
 #define KV_CALL(F) dispatch_bwd_input<F>(a, st)
     KV_FAMILY_SWITCH(d->family, KV_CALL)
