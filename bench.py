@@ -191,12 +191,21 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
         args.gpus = world
     import torch.distributed as dist
+    # Rehearsal hooks for a ONE-GPU box (not used by the driver): KANVIT_SHARE_GPU=1 maps every rank to cuda:0 and
+    # KANVIT_DIST_BACKEND=gloo swaps the transport, so the N > 1 control flow of this file (reducer hooks, barriers, max over
+    # ranks, one line from rank 0) can be exercised where RCCL cannot (it refuses two ranks on one device).
+    if os.environ.get("KANVIT_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("KANVIT_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dp = os.environ.get("KANVIT_FORCE_DP") == "1" and "RANK" in os.environ   # 1-rank rehearsal of the RCCL path
     if world > 1 or force_dp:
         with _StdoutToStderr():
-            dist.init_process_group("nccl", device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
             dist.all_reduce(torch.zeros(1, device=dev))          # forces communicator creation (and its banner) now
             torch.cuda.synchronize()
 
@@ -307,7 +316,8 @@ def main():
             "config": {"workload": args.workload, "model_type": wl["type"], "image": list(wl["chw"]),
                        "n_patches": wl["n_patches"], "n_blocks": wl["n_blocks"], "d_hidden": wl["d"],
                        "n_heads": wl["heads"], "per_gpu_batch": wl["batch"], "global_batch": world * wl["batch"],
-                       "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 0),
+                       "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist.is_initialized() and backend == "nccl" else 0),
+                       "dist_backend": (backend if dist.is_initialized() else None),
                        "optimizer": "Adam(lr=1e-3, fused)", "hip_graph": bool(use_graph), "tuned_gemm_selection": bool(tuned_ok),
                        "kanvit_switches": klib.active_config(), "loss_after": round(final_loss, 4)},
         }
