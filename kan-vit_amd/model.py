@@ -53,6 +53,23 @@ class TransformerBlock(nn.Module):
         return x, feed_forward(h2.reshape(b * n, d), self.ff[0], self.ff[2]).view(b, n, d)   # bias + ReLU in the GEMM epilogue
 
 
+class _ClsToken(torch.autograd.Function):
+    """out[:, 0] + pending[:, 0] (model.py:166-169 reads only the class token; the last block's feed-forward output is still
+    pending, TransformerBlock.run).  The two inputs receive the SAME gradient -- g in row 0, zeros elsewhere -- so backward builds
+    it once (one fill + one copy instead of two of each; the small geometries count launches)."""
+
+    @staticmethod
+    def forward(ctx, out, pending):
+        ctx.shape = out.shape
+        return out[:, 0] + pending[:, 0]
+
+    @staticmethod
+    def backward(ctx, g):
+        full = g.new_zeros(ctx.shape)
+        full[:, 0] = g
+        return full, full
+
+
 def _patch_embedding(kind, in_dim, d):
     if kind in ("vanilla", "flash-attn"):
         return nn.Linear(in_dim, d)
@@ -172,7 +189,7 @@ class VisionTransformer(nn.Module):
             else:                                     # 'flash-attn' models stack bare FlashAttention modules (model.py:113-117)
                 out = blk(out)
         if pending is not None:
-            out = out[:, 0] + pending[:, 0]       # only the class token feeds the head (model.py:166-169)
+            out = _ClsToken.apply(out, pending)   # only the class token feeds the head (model.py:166-169)
         else:
             out = out[:, 0]
         return self.mlp_head(out)
