@@ -1754,6 +1754,160 @@ int launch_bwd(const AttnArgs& a, hipStream_t st) {
     return 0;
 }
 
+// =============================================================================================
+// Small heads (N <= 32, D <= 32; exact fp32): ONE WAVE per (batch, head), 4 heads per work-group, no barriers.
+// train.py's own default geometry is this case (32x32 images, 4x4 patches -> N = 17; d = 64, 8 heads -> D = 8): 1024 heads of a
+// 17x17x8 problem, for which the general kernels (one 512-thread work-group per head, 32-wide padded tiles through LDS) spend
+// 10 + 40 us of launch and fill latency per block.  Here a head is one 32x32 MFMA tile:
+//   S^T[key][q] = K Q^T           A = the lane's own K row, B = the lane's own Q row (half h takes d = h*ceil(D/2) + s)
+//   softmax over keys = over the 16 accumulator registers and the partner lane (l ^ 32), in registers
+//   O^T[d][q]  = V^T P^T          the contraction index (key) is the accumulator REGISTER index: P feeds the matrix pipe as is
+// Backward (same wave, same orientation): S and dP^T = V dO^T recomputed, dS in registers, dQ^T = K^T dS^T straight from
+// registers; dV^T = dO^T P and dK^T = Q^T dS contract over q (the lane index), so P^T and dS^T take one trip through a
+// wave-private LDS tile.  Every output row is the storing lane's own row.
+// =============================================================================================
+__device__ __forceinline__ void attn_small_store_row(float* __restrict__ rowp, const f32x16& acc, int hf, int D, float mul) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = kv_acc_row(r, hf);
+        if (d < D) rowp[d] = acc[r] * mul;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const AttnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= a.B * a.H) return;
+    const int bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, D = a.D, DHc = (D + 1) / 2;
+    const bool row_ok = l31 < N;
+    const float* qrow = a.q + bi * a.qsb + hi * a.qsh + (long long)(row_ok ? l31 : 0) * a.qsn;
+    const float* krow = a.k + bi * a.ksb + hi * a.ksh + (long long)(row_ok ? l31 : 0) * a.ksn;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    float vt[16];                                  // V[key(r, h)][d = this lane]: the A operand of the second product
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = kv_acc_row(r, hf);
+        vt[r] = (key < N && l31 < D) ? vb[(long long)key * a.vsn + l31] : 0.0f;
+    }
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+    for (int s = 0; s < DHc; ++s) {
+        const int d = hf * DHc + s;
+        const bool ok = row_ok && d < D;
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? krow[d] : 0.0f, ok ? qrow[d] : 0.0f, sacc, 0, 0, 0);
+    }
+    const float sc2 = a.scale * LOG2E;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = kv_acc_row(r, hf);
+        if (key >= N || (a.causal && key > l31)) sacc[r] = -INFINITY;
+        mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = exp2f((sacc[r] - mx) * sc2);       // masked entries: exp2(-inf) = 0
+        sacc[r] = p;
+        sum += p;
+    }
+    sum += __shfl_xor(sum, 32);
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[r], sacc[r], oacc, 0, 0, 0);
+    if (row_ok) {
+        attn_small_store_row(a.out + bi * a.osb + hi * a.osh + (long long)l31 * a.osn, oacc, hf, D, 1.0f / sum);
+        if (hf == 0 && a.lse) a.lse[(long long)bh * N + l31] = mx * a.scale + logf(sum);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const AttnArgs a) {
+    __shared__ float tiles[4][2][32 * 33];         // per wave: P^T[key][q] and dS^T[key][q]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= a.B * a.H) return;
+    const int bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, D = a.D, DHc = (D + 1) / 2;
+    const bool row_ok = l31 < N;
+    const long long r0 = row_ok ? l31 : 0;
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* ob = a.o + bi * a.osb + hi * a.osh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    // gathers for the three register/LDS-operand products: lane = feature d, 16 rows each
+    float kt[16], dot[16], qt[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = kv_acc_row(r, hf);                                   // dQ^T: contraction over keys in register order
+        kt[r] = (key < N && l31 < D) ? kb[(long long)key * a.ksn + l31] : 0.0f;
+        const int qq = 2 * r + hf;                                           // dV^T / dK^T: contraction over q, k-step r, half h
+        const bool ok = qq < N && l31 < D;
+        dot[r] = ok ? dob[(long long)qq * a.osn + l31] : 0.0f;
+        qt[r] = ok ? qb[(long long)qq * a.qsn + l31] : 0.0f;
+    }
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sacc[r] = 0.0f;
+        pacc[r] = 0.0f;
+    }
+    float dl = 0.0f;
+    for (int s = 0; s < DHc; ++s) {
+        const int d = hf * DHc + s;
+        const bool ok = row_ok && d < D;
+        const float kv = ok ? kb[r0 * a.ksn + d] : 0.0f, qv = ok ? qb[r0 * a.qsn + d] : 0.0f;
+        const float vv = ok ? vb[r0 * a.vsn + d] : 0.0f, dv = ok ? dob[r0 * a.osn + d] : 0.0f;
+        const float ov = ok ? ob[r0 * a.osn + d] : 0.0f;
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, sacc, 0, 0, 0);     // S^T[key][q]
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, dv, pacc, 0, 0, 0);     // dP^T[key][q]
+        dl += dv * ov;                                                           // rowsum(dO * O) of this lane's query (utils.py:286)
+    }
+    dl += __shfl_xor(dl, 32);
+    const float sc2 = a.scale * LOG2E;
+    const float lse2 = row_ok ? a.lse_in[(long long)bh * N + l31] * LOG2E : INFINITY;      // pad queries: p = 0
+    float* pt = tiles[wave][0];
+    float* dst = tiles[wave][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = kv_acc_row(r, hf);
+        float p = exp2f(sacc[r] * sc2 - lse2);
+        if (key >= N || (a.causal && key > l31)) p = 0.0f;
+        const float ds = p * a.scale * (pacc[r] - dl);                           // utils.py:278-287
+        sacc[r] = p;
+        pacc[r] = ds;
+        pt[key * 33 + l31] = p;
+        dst[key * 33 + l31] = ds;
+    }
+    f32x16 dqacc, dkacc, dvacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        dqacc[r] = 0.0f;
+        dkacc[r] = 0.0f;
+        dvacc[r] = 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[r], pacc[r], dqacc, 0, 0, 0);    // dQ^T[d][q]
+    __builtin_amdgcn_wave_barrier();               // the tile is wave-private: LDS executes this wave's writes before its reads
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                 // B[k = q = 2r + h][col = key = lane]
+        dvacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dot[r], pt[l31 * 33 + 2 * r + hf], dvacc, 0, 0, 0);          // dV^T[d][key]
+        dkacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qt[r], dst[l31 * 33 + 2 * r + hf], dkacc, 0, 0, 0);          // dK^T[d][key]
+    }
+    if (row_ok) {
+        attn_small_store_row(a.dq + bi * a.qsb + hi * a.qsh + (long long)l31 * a.qsn, dqacc, hf, D, 1.0f);
+        attn_small_store_row(a.dk + bi * a.ksb + hi * a.ksh + (long long)l31 * a.ksn, dkacc, hf, D, 1.0f);
+        attn_small_store_row(a.dv + bi * a.vsb + hi * a.vsh + (long long)l31 * a.vsn, dvacc, hf, D, 1.0f);
+    }
+}
+
+bool attn_small_ok(const kanvit_attn_desc* d) { return d->N <= 32 && d->D <= 32 && !kv_config().attn_v1 && !kv_config().attn_v2; }
+
 }  // namespace
 
 extern "C" {
@@ -1773,6 +1927,11 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
     a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
+    if (attn_small_ok(d)) {           // one wave per head (exact fp32; the bf16 flag allows, never requires, bf16 products)
+        hipLaunchKernelGGL(attn_small_fwd_kernel, dim3((unsigned)((d->B * d->H + 3) / 4)), dim3(256), 0, st, a);
+        KV_LAUNCH_CHECK("attn_small_fwd_kernel");
+        return 0;
+    }
     if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !kv_config().no_bf16)
         return d->D <= 32 ? dispatch_fwd<1, true>(a, st) : dispatch_fwd<2, true>(a, st);
     return d->D <= 32 ? dispatch_fwd<1, false>(a, st) : dispatch_fwd<2, false>(a, st);
@@ -1812,6 +1971,11 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     a.ds = attn_ds_spill(d) ? (float*)((char*)workspace + attn_delta_bytes(d)) : nullptr;
     a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
+    if (attn_small_ok(d)) {
+        hipLaunchKernelGGL(attn_small_bwd_kernel, dim3((unsigned)((d->B * d->H + 3) / 4)), dim3(256), 0, st, a);
+        KV_LAUNCH_CHECK("attn_small_bwd_kernel");
+        return 0;
+    }
     const long long rows = (long long)d->B * d->H * d->N;
     // the third-form fp32 kernels form rowsum(dO*O) themselves; every other path reads it from the workspace
     const size_t lds3 = sizeof(float) * ((size_t)2 * a.nkt * 32 * kv_pad4(d->D) + 2 * (size_t)a.nkt * 32);
