@@ -109,9 +109,11 @@ def test_bf16_mfma_attention_close_to_fp32(n, d):
             assert 0 < err < 3e-2, err
 
 
-@pytest.mark.parametrize("b,h,n,d,causal", [(128, 8, 17, 8, False), (3, 5, 32, 32, True), (2, 2, 1, 2, False), (7, 3, 31, 18, True)])
+@pytest.mark.parametrize("b,h,n,d,causal", [(128, 8, 17, 8, False), (3, 5, 32, 32, True), (2, 2, 1, 2, False), (7, 3, 31, 18, True),
+                                                 (128, 2, 50, 32, False), (3, 3, 33, 32, True), (5, 1, 64, 16, False), (2, 7, 47, 8, True)])
 def test_small_head_kernels_packed_layout_and_determinism(b, h, n, d, causal):
-    """N <= 32, D <= 32 (train.py's default geometry is N = 17, D = 8): one wave per head.  Against the fp64 oracle through the
+    """N <= 32, D <= 32 (train.py's default geometry is N = 17, D = 8): one wave per head (the cases with N > 32 run the
+    third-form kernels through the same checks).  Against the fp64 oracle through the
     packed qkv layout MSA uses, bitwise run-to-run, and equal to the general kernels (KANVIT_ATTN_V1) to fp32 rounding."""
     import os
     from kanvit import _lib, ops
