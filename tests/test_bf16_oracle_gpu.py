@@ -160,6 +160,9 @@ def test_attention_bf16(n, d):
     o.backward(do.to(DEV))
     got = (o, qg.grad, kg.grad, vg.grad)
     for name, a, b_t, b_e in zip(("o", "dq", "dk", "dv"), got, res[True], res[False]):
+        if n <= 32 and d <= 32:      # the one-wave-per-head kernels are exact fp32 in either mode (the flag allows bf16, never requires it)
+            assert maxrel(a, b_e) < 1e-5, (name, maxrel(a, b_e))
+            continue
         assert maxrel(a, b_t) < TIGHT, (name, maxrel(a, b_t))
         assert 1e-5 < fro(a, b_e) < 1.5 * LOOSE, (name, fro(a, b_e))           # gradients: three chained bf16 products
 
