@@ -3279,6 +3279,15 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
 
 }  // namespace
 
+static KvTinyArgs tiny_args(const kanvit_layer_desc* d) {
+    KvTinyArgs t{};
+    t.M = d->M; t.ldx = d->ldx; t.ldy = d->ldy; t.bp_stride = d->bparam_stride;
+    t.family = d->family; t.I = d->I; t.O = d->O; t.groups = d->groups; t.xmod = d->x_group_mod; t.G = d->G;
+    t.GP = gp_of(d); t.K = d->I * t.GP; t.order = d->spline_order; t.nk = d->G + d->spline_order + 1;
+    t.has_base = d->has_base; t.flags = d->flags;
+    return t;
+}
+
 thread_local char g_kanvit_err[512] = "";
 
 // ---- run-time switches: read once, reported, never consulted through getenv on the launch path ----
@@ -3296,6 +3305,7 @@ static void kv_config_load() {
     c.no_ws = flag("KANVIT_NO_WS");
     c.no_bf16 = flag("KANVIT_NO_BF16");
     c.no_fused_ln = flag("KANVIT_NO_FUSED_LN");
+    c.no_tiny = flag("KANVIT_NO_TINY");
     c.attn_v1 = flag("KANVIT_ATTN_V1");
     c.attn_v2 = flag("KANVIT_ATTN_V2");
     c.attn_no_ds = flag("KANVIT_ATTN_NO_DS");
@@ -3304,8 +3314,8 @@ static void kv_config_load() {
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
-             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
+             "no_reg=%d no_reg_bw=%d reg_bw_bspline=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
+             c.no_reg, c.no_reg_bw, c.reg_bw_bspline, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }
@@ -3348,6 +3358,11 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
     if (d->family == KANVIT_RBF && u && d->ldu < (int64_t)d->groups * d->I)
         return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: ldu < groups*I");
     if (d->M == 0) return 0;
+    if (kv_tiny_ok(d)) {              // tiny per-head layers (I, O <= 16): vector-pipe kernels, csrc/kan_tiny.hip
+        KvTinyArgs t = tiny_args(d);
+        t.x = x; t.w = w; t.bp = bparams; t.bias = bias; t.y = y;
+        return kv_tiny_fwd(t, (hipStream_t)stream);
+    }
     LayerArgs a = base_args(d);
     a.x = x;
     a.u = u;
@@ -3504,6 +3519,11 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
     if (d->family == KANVIT_SINE && (d->groups / d->x_group_mod) * 4 * d->G > 4096)
         return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: SINE G too large");
     if (d->M == 0) return 0;
+    if (kv_tiny_ok(d)) {
+        KvTinyArgs t = tiny_args(d);
+        t.x = x; t.w = w; t.bp = bparams; t.dy = dy; t.dx = dx;
+        return kv_tiny_bwd_input(t, (hipStream_t)stream);
+    }
     LayerArgs a = base_args(d);
     a.x = x;
     a.u = u;
@@ -3545,6 +3565,10 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
 
 size_t kanvit_layer_bwd_weight_workspace(const kanvit_layer_desc* d) {
     if (!d || gp_of(d) < 1 || d->groups < 1 || d->I < 1 || d->O < 1) return 0;
+    if (kv_tiny_ok(d)) {
+        const int s = kv_tiny_slabs(d);
+        return s > 1 ? sizeof(float) * (size_t)s * d->groups * ((size_t)d->I * gp_of(d)) * d->O : 0;
+    }
     const BwRegPlan pr = plan_bwd_weight_reg(d);
     if (pr.ok) return pr.ws_bytes;
     const BwPlan p = plan_bwd_weight(d);
@@ -3564,10 +3588,28 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
     if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: family %d needs bparams", d->family);
     if (d->family == KANVIT_RBF && u && d->ldu < (int64_t)d->groups * d->I)
         return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: ldu < groups*I");
-    const BwPlan p = plan_bwd_weight(d);
     const size_t need = kanvit_layer_bwd_weight_workspace(d);
     if (need > 0 && (!workspace || workspace_bytes < need))
         return kv_fail(KANVIT_ENOMEM, "kanvit_layer_bwd_weight: workspace %zu bytes < required %zu", workspace_bytes, need);
+    if (kv_tiny_ok(d)) {
+        hipStream_t st = (hipStream_t)stream;
+        KvTinyArgs t = tiny_args(d);
+        t.x = x; t.bp = bparams; t.dy = dy;
+        t.slabs = kv_tiny_slabs(d);
+        t.rows_per_slab = ((d->M + t.slabs - 1) / t.slabs + 63) / 64 * 64;
+        t.slabs = (int)((d->M + t.rows_per_slab - 1) / t.rows_per_slab);
+        t.slab = t.slabs > 1 ? (float*)workspace : dw;
+        if (int rc = kv_tiny_bwd_weight(t, st)) return rc;
+        if (t.slabs > 1) {
+            const long long total = (long long)d->groups * t.K * d->O;
+            long long nb = (total + 255) / 256;
+            if (nb > 8 * N_CU) nb = 8 * N_CU;
+            hipLaunchKernelGGL(kan_slab_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)workspace, dw, total, t.slabs);
+            KV_LAUNCH_CHECK("kan_slab_reduce_kernel");
+        }
+        return 0;
+    }
+    const BwPlan p = plan_bwd_weight(d);
     LayerArgs a = base_args(d);
     a.x = x;
     a.u = u;

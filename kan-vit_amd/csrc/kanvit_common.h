@@ -45,6 +45,7 @@ struct KvConfig {
     int no_pipe;         // KANVIT_NO_PIPE         fp32 register kernels without the one-step-ahead LDS fragment prefetch (round-1 form)
     int no_ws;           // KANVIT_NO_WS           W-stationary bf16 forward off
     int no_bf16;         // KANVIT_NO_BF16         ignore KANVIT_FLAG_BF16_MFMA (exact fp32 kernels)
+    int no_tiny;         // KANVIT_NO_TINY         the vector-pipe kernels for tiny per-head layers (I, O <= 16) off
     int no_fused_ln;     // KANVIT_NO_FUSED_LN     kanvit_layer_ln_fusable() answers 0: FastKAN's LayerNorm stays a separate op
     int attn_v1;         // KANVIT_ATTN_V1         first-form attention kernels
     int attn_v2;         // KANVIT_ATTN_V2         second-form fp32 attention kernels (round 1) instead of the pipelined third form
@@ -53,7 +54,7 @@ struct KvConfig {
     int attn_grid;       // KANVIT_ATTN_GRID       work-groups of the persistent attention kernels (tuning; 0 = one round of resident ones)
     int bf16_nsh;        // KANVIT_BF16_NSH        LDS-tile bf16 forward: groups per basis tile (tuning)
     int bf16_ic;         // KANVIT_BF16_IC         LDS-tile bf16 forward: feature chunk cap (tuning)
-    char text[384];
+    char text[416];
 };
 const KvConfig& kv_config();
 
@@ -77,6 +78,25 @@ static inline hipError_t kv_allow_lds(K kernel, size_t bytes) {
             __atomic_fetch_or(&kv_mask_, kv_bit_, __ATOMIC_RELAXED);                              \
         }                                                                                         \
     } while (0)
+
+// tiny per-head layers on the vector pipe (csrc/kan_tiny.hip), called by kan_layer.hip's entry points
+struct KvTinyArgs {
+    const float* x;
+    const float* w;
+    const float* bp;
+    const float* bias;
+    const float* dy;
+    float* y;
+    float* dx;
+    float* slab;
+    long long M, ldx, ldy, bp_stride, rows_per_slab;
+    int family, I, O, groups, xmod, G, GP, K, order, nk, has_base, flags, slabs;
+};
+bool kv_tiny_ok(const kanvit_layer_desc* d);
+int kv_tiny_slabs(const kanvit_layer_desc* d);
+int kv_tiny_fwd(const KvTinyArgs& a, hipStream_t st);
+int kv_tiny_bwd_input(const KvTinyArgs& a, hipStream_t st);
+int kv_tiny_bwd_weight(const KvTinyArgs& a, hipStream_t st);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libkanvit.so")
-SOURCES = ["kan_layer.hip", "attention.hip", "addln.hip", "split3.hip", "ff_small.hip"]
+SOURCES = ["kan_layer.hip", "attention.hip", "addln.hip", "split3.hip", "ff_small.hip", "kan_tiny.hip"]
 HEADERS = ["kan_basis.h", "kanvit_common.h", os.path.join(INCLUDE, "kanvit.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=on", "-fno-finite-math-only"]
 

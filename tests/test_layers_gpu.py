@@ -278,3 +278,46 @@ def test_bspline_non_uniform_or_differing_grids_take_the_general_path():
     want = torch.cat(want, dim=1)
     assert max_err(got.cpu(), want) < FWD_TOL * max(1.0, float(want.abs().max()))
     assert max_err(got.cpu()[:, :64 * 3], ref[:, :64 * 3]) < 1e-6        # untouched layers unchanged
+
+
+@pytest.mark.parametrize("fam", ["vanilla", "cheby", "efficientkan"])
+def test_tiny_head_kernels_against_oracle_and_general_path(fam, monkeypatch):
+    """train.py's default geometry (d = 64, 8 heads -> per-head layers of 8 -> 8 features, M = 128 x 17 rows): the vector-pipe
+    kernels of csrc/kan_tiny.hip.  Forward and every gradient against the fp64 oracle, and against the general (LDS-tile) kernels
+    they replace (KANVIT_NO_TINY=1)."""
+    from attention import MSA
+    from kanvit import _lib, grouped
+    from tests.test_headline_parity_gpu import _oracle_qkv
+    torch.manual_seed(21)
+    d, h, rows = 64, 8, 128 * 17
+    msa = MSA(d, h, type=fam)
+    x = torch.randn(rows, d)
+    w = torch.randn(rows, 3 * d)
+    yo, gxo, gpo = _oracle_qkv(msa, x, w, h)
+    msa = msa.to(DEV)
+
+    def run():
+        msa.zero_grad()
+        xg = x.to(DEV).requires_grad_(True)
+        y = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, xg)
+        (y * w.to(DEV)).sum().backward()
+        return y.detach(), xg.grad, {k: v.grad.clone() for k, v in msa.named_parameters() if v.grad is not None}
+
+    y, gx, gp = run()
+    assert max_err(y.cpu(), yo) < 2e-5 * max(1.0, float(yo.abs().max()))
+    assert rel_err(gx.cpu(), gxo) < GRAD_TOL
+    assert set(gp) == set(gpo)
+    for k, g in gpo.items():
+        assert rel_err(gp[k].cpu(), g) < GRAD_TOL, (k, rel_err(gp[k].cpu(), g))
+    y2, gx2, gp2 = run()
+    assert torch.equal(y, y2) and torch.equal(gx, gx2) and all(torch.equal(gp[k], gp2[k]) for k in gp)      # deterministic
+    monkeypatch.setenv("KANVIT_NO_TINY", "1")
+    _lib.reload_config()
+    try:
+        y0, gx0, gp0 = run()
+    finally:
+        monkeypatch.delenv("KANVIT_NO_TINY")
+        _lib.reload_config()
+    assert rel_err(y, y0) < 1e-5 and rel_err(gx, gx0) < 1e-5
+    for k in gp0:
+        assert rel_err(gp[k], gp0[k]) < 1e-5, k
