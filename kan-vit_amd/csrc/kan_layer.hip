@@ -662,7 +662,12 @@ template <int FAM, int GP, int KT, bool SHARED>
 __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2) void kan_bwd_input_reg_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KCT = 32 * KT;
-    constexpr int WS = KCT + 1;
+    // W^T image: element (n = h*16 + s, k) at s*WS2 + h*HOFF + k.  HOFF = 32 (mod 64) puts the two lane halves of a fragment
+    // read on disjoint bank halves (with the old [2s+h][KCT+1] rows the halves were 33 banks apart: one bank shared, every
+    // ds_read2_b32 took 3 cycles instead of 2 -- the 16.7 % LDS conflict rate of profiles/r02_sq_pmc_fp32.md); WS2 = 2 (mod 16)
+    // spreads the staging writes (8 lanes: s = e + 4j', h = 0/1, 8 consecutive k) over all 64 banks.
+    constexpr int HOFF = (KCT % 64 == 32) ? KCT : KCT + 32;
+    constexpr int WS2 = ((HOFF + KCT + 13) / 16) * 16 + 2;
     constexpr int FPH = (16 * KT) / GP;           // features per lane half and chunk
     constexpr int IC = 2 * FPH;
     constexpr bool RBF = (FAM == KV_RBF);
@@ -675,8 +680,8 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
     const int row = wave * 32 + l31;
     const bool row_ok = row < mrem;
     const long long grow = m0 + (row_ok ? row : 0);
-    float* W_s = smem;                            // [2][32][WS]
-    constexpr int WSZ = 32 * WS;
+    float* W_s = smem;                            // [2][16][WS2]
+    constexpr int WSZ = 16 * WS2;
     constexpr bool SINE = (FAM == KV_SINE);
     float* dfq_s = W_s + 2 * WSZ;                 // SINE: [nshare][4 waves][GP] partial d loss / d freq of this row tile
     if constexpr (SINE) {
@@ -722,9 +727,8 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
                 const int kr = v >> 3;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int n = nofs[q] + e;                    // n within the 32-column chunk
-                    const int lr = ((n & 15) << 1) | (n >> 4);    // LDS row (s, h): n = h*16 + s  ->  row 2*s + h
-                    dst[lr * WS + kr] = wreg[q][e];
+                    const int n = nofs[q] + e;                    // n within the 32-column chunk: n = h*16 + s
+                    dst[(n & 15) * WS2 + (n >> 4) * HOFF + kr] = wreg[q][e];
                 }
             }
         }
@@ -783,7 +787,7 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
         // contraction over this chunk's 32 dY columns: A = W^T rows (LDS, lane = k row), B = dY of this lane's row
         // W^T fragments are read ONE k-step ahead into a second register set (same reasoning as the forward kernel: an LDS
         // read -> wait -> MFMA chain on one register pair leaves the matrix pipe idle for the read latency on every pair)
-        const float* wp = W_s + (t & 1) * WSZ + hf * WS + l31;
+        const float* wp = W_s + (t & 1) * WSZ + hf * HOFF + l31;
         float wa[2][KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) wa[0][kt] = wp[kt * 32];
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
         for (int s2 = 0; s2 < 16; ++s2) {
             if (s2 + 1 < 16) {
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) wa[(s2 + 1) & 1][kt] = wp[(2 * (s2 + 1)) * WS + kt * 32];
+                for (int kt = 0; kt < KT; ++kt) wa[(s2 + 1) & 1][kt] = wp[(s2 + 1) * WS2 + kt * 32];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2945,7 +2949,8 @@ int launch_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
         ((uintptr_t)a.dx & 15) || ((uintptr_t)a.dy & 15) || ((uintptr_t)a.w & 15))
         return 1;
     if ((long long)IC * GP * a.O >= (1LL << 30)) return 1;
-    const size_t lds = sizeof(float) * (2 * 32 * (32 * KT + 1) + (FAM == KV_SINE ? (size_t)nshare * 4 * GP : 0));
+    constexpr int KCT_ = 32 * KT, HOFF_ = (KCT_ % 64 == 32) ? KCT_ : KCT_ + 32, WS2_ = ((HOFF_ + KCT_ + 13) / 16) * 16 + 2;
+    const size_t lds = sizeof(float) * (2 * 16 * WS2_ + (FAM == KV_SINE ? (size_t)nshare * 4 * GP : 0));
     if (FAM == KV_SINE && !a.dparam) return 1;
     const bool shared = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare > 1;
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
