@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void kan_tiny_fwd_kernel(const KvTinyArgs a) {
     const int g = blockIdx.y, gx = g % a.xmod;
     // the group's weights ([K][O] <= 4 KB) go to LDS once: every thread then reads them as broadcasts (a chain of scalar
     // loads -- one s_load + wait per (i, j) -- measured 20 us for this launch)
-    __shared__ __attribute__((aligned(16))) float w_s[256 * OT];      // [K][OT], columns past O zero: the inner loop needs no guard
+    __shared__ __attribute__((aligned(16))) float w_s[200 * OT];      // [K][OT], columns past O zero: the inner loop needs no guard
     for (int e = threadIdx.x; e < a.K * OT; e += 256) {               // (a guard per output column compiled to a branch + LDS wait each)
         const int k = e / OT, o = e - k * OT;
         w_s[e] = o < a.O ? a.w[((long long)g * a.K + k) * a.O + o] : 0.0f;
@@ -194,7 +194,7 @@ bool kv_tiny_ok(const kanvit_layer_desc* d) {
     else if (fam == KANVIT_FOURIER) gp = 2 * d->G;
     else if (fam == KANVIT_BSPLINE && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) gp = d->G + d->has_base;
     else return false;
-    if (gp < 1 || d->I * gp > 255 || d->I * gp * d->O > 1024) return false;
+    if (gp < 1 || d->I * gp > 200 || d->I * gp * d->O > 1024) return false;      // K <= 200: the weight gradient's phi tile [64][K + 1] stays under 64 KB of LDS
     if (d->x_group_mod < 1 || d->groups % d->x_group_mod || (d->groups / d->x_group_mod) * d->I * gp * 16 > 15 * 1024) return false;
     return d->M >= 64;                               // fewer rows: the general kernels' single tile is as good
 }
