@@ -236,3 +236,42 @@ def test_non_default_rbf_grid_takes_the_general_kernels():
     assert rel_err(xg.grad.cpu(), xd.grad) < TOL
     default = FastKANLayer(64, 64).to(DEV)
     assert default.kan_cfg().flags & _lib.FLAG_UNIFORM_KNOTS and ops.ln_fusable(default.kan_cfg(), 300)
+
+
+@pytest.mark.parametrize("scale,shift", [(1.0, 0.0), (8.0, 0.0), (3.0, 6.0), (3.0, -9.0), (40.0, 0.0)])
+def test_rbf_recurrence_over_the_whole_argument_range(scale, shift):
+    """The register kernels form FastKAN's eight Gaussians from two exp anchors and a recurrence (kan_basis.h::kv_rbf8).  Drive the
+    normalised input far outside the grid ([-2, 2]): u = scale * xhat + shift reaches |u| ~ 150 at scale 40, where every basis
+    value underflows, and sits on the grid's edges for the shifted cases.  Forward and all gradients against the fp64 oracle."""
+    from kanvit import ops
+    from models.fastkan import FastKANLayer
+    torch.manual_seed(5)
+    layer = FastKANLayer(64, 64)
+    with torch.no_grad():
+        layer.layernorm.weight.fill_(scale)
+        layer.layernorm.bias.fill_(shift)
+    x = torch.randn(512, 64) * 2.0
+    w = torch.randn(512, 64)
+    yo, gxo, gpo = _oracle_layer(layer, x, w)
+    layer = layer.to(DEV)
+    assert ops.ln_fusable(layer.kan_cfg(), 512)
+    xg = x.to(DEV).requires_grad_(True)
+    y = layer(xg)
+    (y * w.to(DEV)).sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(xg.grad).all()
+    assert max_err(y.cpu(), yo) < 2e-5 * max(1.0, float(yo.abs().max()))
+    assert close(xg.grad.cpu(), gxo, rtol=TOL, atol=1e-6), rel_err(xg.grad.cpu(), gxo)
+    for k, g in gpo.items():
+        got = dict(layer.named_parameters())[k].grad.cpu()
+        assert close(got, g, rtol=TOL, atol=1e-6), (k, rel_err(got, g))
+
+
+def test_rbf_recurrence_keeps_nan_a_nan():
+    from models.fastkan import FastKANLayer
+    torch.manual_seed(6)
+    layer = FastKANLayer(64, 64).to(DEV)
+    x = torch.randn(300, 64, device=DEV)
+    x[17, 5] = float("nan")
+    y = layer(x)
+    assert torch.isnan(y[17]).all()                        # the LayerNorm spreads a NaN over its row; the clamp in kv_rbf8 must not hide it
+    assert torch.isfinite(y[:17]).all() and torch.isfinite(y[18:]).all()
