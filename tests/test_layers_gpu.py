@@ -321,3 +321,19 @@ def test_tiny_head_kernels_against_oracle_and_general_path(fam, monkeypatch):
     assert rel_err(y, y0) < 1e-5 and rel_err(gx, gx0) < 1e-5
     for k in gp0:
         assert rel_err(gp[k], gp0[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("fam", ["cheby", "efficientkan", "fourier"])
+@pytest.mark.parametrize("shape", [(300, 5, 3), (64, 16, 16), (1000, 8, 8), (257, 16, 4), (90, 1, 12)])
+def test_tiny_single_layers_against_oracle(fam, shape):
+    """Single layers with I, O <= 16 and M >= 64 (odd sizes included) take the vector-pipe kernels of csrc/kan_tiny.hip."""
+    m, i, o = shape
+    torch.manual_seed(m + 7 * i + o)
+    layer = make_layer(fam, i, o, big=False)
+    x = torch.randn(m, i) * (1.5 if fam != "cheby" else 1.0)
+    y, gx, gp = run_gpu(layer, x)
+    yo, gxo, gpo = oracle_run(layer, x)
+    assert max_err(y, yo) < FWD_TOL * max(1.0, float(yo.abs().max())), (fam, shape, max_err(y, yo))
+    assert rel_err(gx, gxo) < GRAD_TOL, (fam, shape, "grad_x", rel_err(gx, gxo))
+    for k, g in gpo.items():
+        assert rel_err(gp[k], g) < GRAD_TOL, (fam, shape, k, rel_err(gp[k], g))
