@@ -65,6 +65,38 @@ class _StdoutToStderr:
         return False
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start the N ranks ourselves -- one CHILD process
+    per GPU under torch.distributed.run, exactly the command line the docstring gives -- BEFORE this process has made any GPU
+    call (it never does: it only relays), pass rank 0's single JSON line through to stdout and return the launcher's exit
+    code.  No exec: a process that may have touched the GPU must not be replaced on this pool."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:                                     # stderr of the ranks is inherited (progress, warnings)
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def host_cores():
     """CPU cores this process may really use: affinity mask, cgroup quota, and the GPU box's per-GPU
     share (16).  os.cpu_count() reports all 256 host threads and oversubscribes torch ~16x."""
@@ -181,16 +213,27 @@ def main():
                     help="bf16 autocast for the stock dense ops (FF GEMMs); the kanvit kernels stay fp32 at their boundary")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="capture the whole train step in a HIP graph (auto: single GPU and a launch-bound workload)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="(test hook) bring the process group up, all-reduce one number, print a stub line and exit: exercises the "
+                         "self-launch / relay path without a GPU (KANVIT_DIST_BACKEND=gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))                    # plain `python bench.py --gpus N`: spawn the ranks, relay the line
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
-        args.gpus = world
+        args.gpus = world                                   # under a launcher the launcher's world size is the truth
     import torch.distributed as dist
+    if args.rendezvous_only:
+        dist.init_process_group(os.environ.get("KANVIT_DIST_BACKEND", "gloo"))
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": "rendezvous-only", "n_gpus": world, "sum_of_ones": float(t)}), flush=True)
+        dist.destroy_process_group()
+        return
     # Rehearsal hooks for a ONE-GPU box (not used by the driver): KANVIT_SHARE_GPU=1 maps every rank to cuda:0 and
     # KANVIT_DIST_BACKEND=gloo swaps the transport, so the N > 1 control flow of this file (reducer hooks, barriers, max over
     # ranks, one line from rank 0) can be exercised where RCCL cannot (it refuses two ranks on one device).

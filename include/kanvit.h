@@ -28,6 +28,11 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define KANVIT_ABI_VERSION 5
 
 /* error codes */
@@ -279,6 +284,10 @@ const char* kanvit_config(void);
 int kanvit_config_reload(void);
 /* number of HIP devices visible, or a negative error code; does not initialise a context */
 int kanvit_device_count(void);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -116,13 +116,33 @@ def lib():
     return _lib
 
 
+_py_switches = None
+
+
+def py_switches() -> dict:
+    """The Python-side switches (kanvit/dense.py: which feed-forward path runs), read from the environment ONCE like the
+    library's own (never on the launch path) and echoed by active_config(), so a bench line states what it timed:
+      ff           KANVIT_FF=bf16x3       opt-in three-term bf16 split-product feed-forward (default fp32)
+      no_ff_small  KANVIT_NO_FF_SMALL     stock GEMMs instead of the fused small feed-forward (csrc/ff_small.hip)
+      no_lnff      KANVIT_NO_LNFF         separate add+LayerNorm in front of the fused small feed-forward"""
+    global _py_switches
+    if _py_switches is None:
+        _py_switches = {"ff": os.environ.get("KANVIT_FF", ""), "no_ff_small": int(bool(os.environ.get("KANVIT_NO_FF_SMALL"))),
+                        "no_lnff": int(bool(os.environ.get("KANVIT_NO_LNFF")))}
+    return _py_switches
+
+
 def active_config() -> str:
-    """The library's kernel-selection switches as read from KANVIT_* at load ("name=value ..."; all zero = defaults)."""
-    return lib().kanvit_config().decode()
+    """The kernel-selection switches as read from KANVIT_* at load ("name=value ..."; all zero / empty = defaults): the
+    library's (KvConfig) followed by the Python-side ones (py_switches)."""
+    ps = py_switches()
+    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']}"
 
 
 def reload_config() -> str:
     """Re-read the KANVIT_* environment switches (tests switch kernels with it; never needed in production)."""
+    global _py_switches
+    _py_switches = None
     lib().kanvit_config_reload()
     return active_config()
 

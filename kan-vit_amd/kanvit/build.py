@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libkanvit.so")
 SOURCES = ["kan_layer.hip", "attention.hip", "addln.hip", "split3.hip", "ff_small.hip", "kan_tiny.hip"]
 HEADERS = ["kan_basis.h", "kanvit_common.h", os.path.join(INCLUDE, "kanvit.h")]
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=on", "-fno-finite-math-only"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=on", "-fno-finite-math-only", "-fvisibility=hidden"]
 
 
 def _hipcc():

@@ -8,10 +8,10 @@ the token axis into S slabs -- one batched GEMM into [S, N, K] partials plus an 
 slab-then-reduce scheme the KAN weight-gradient kernel uses -- fills the chip: 0.83 ms, 143 TFLOP/s
 (tools/probe_wgrad.py).  Deterministic (fixed summation order), and slightly MORE accurate than the single long
 contraction."""
-import os
-
 import torch
 import torch.nn.functional as F
+
+from . import _lib
 
 _TILE = 256
 _HALF = (torch.bfloat16, torch.float16)
@@ -105,7 +105,6 @@ FF_MODE = "fp32"
 
 
 def _split3(x: torch.Tensor, pattern: int, bias=None, relu=False, mask=None) -> torch.Tensor:
-    from . import _lib
     import ctypes as C
     L = _lib.lib()
     M, K = x.shape
@@ -171,7 +170,7 @@ class _FFSmallFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, w1, b1, w2, b2):
-        from . import _lib, ops
+        from . import ops
         x, w1, b1, w2, b2 = (t.contiguous() for t in (x, w1, b1, w2, b2))
         M, D = x.shape
         F_ = w1.shape[0]
@@ -185,7 +184,7 @@ class _FFSmallFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        from . import _lib, ops
+        from . import ops
         import ctypes as C
         x, w1, b1, w2 = ctx.saved_tensors
         M, D = x.shape
@@ -212,7 +211,7 @@ class _LnFFSmallFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, delta, gamma, beta, w1, b1, w2, b2, eps):
-        from . import _lib, ops
+        from . import ops
         D = x.shape[-1]
         x2 = x.contiguous().view(-1, D)
         d2 = None if delta is None else delta.contiguous().view(-1, D)
@@ -234,7 +233,7 @@ class _LnFFSmallFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gs, gy):
-        from . import _lib, ops
+        from . import ops
         import ctypes as C
         s, mean, rstd, gamma, beta, w1, b1, w2 = ctx.saved_tensors
         M, D = s.shape
@@ -263,23 +262,31 @@ def ln_feed_forward(x: torch.Tensor, delta, norm: torch.nn.LayerNorm, lin1: torc
     from . import ops
     d = x.shape[-1]
     if (norm.elementwise_affine and norm.bias is not None and tuple(norm.normalized_shape) == (d,) and (delta is None or delta.shape == x.shape)
-            and not os.environ.get("KANVIT_NO_LNFF") and _ff_small_ok(x.reshape(-1, d), lin1, lin2)):
+            and not _lib.py_switches()["no_lnff"] and _ff_small_ok(x.reshape(-1, d), lin1, lin2)):
         return _LnFFSmallFn.apply(x, delta, norm.weight, norm.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm.eps)
     s, h = ops.add_layernorm(x, delta, norm)
     return s, feed_forward(h.reshape(-1, d), lin1, lin2).view(x.shape)
 
 
+def ff_mode() -> str:
+    """"fp32" or "bf16x3": KANVIT_FF (read once, _lib.py_switches) overrides the module default FF_MODE."""
+    return _lib.py_switches()["ff"] or FF_MODE
+
+
+def ff_small_supported(d: int, f: int) -> bool:
+    """Host-only query: does the fused small feed-forward (csrc/ff_small.hip) exist for Linear(d, f) -> ReLU -> Linear(f, d)?"""
+    return (not _lib.py_switches()["no_ff_small"]) and bool(_lib.lib().kanvit_ff_small_supported(d, f))
+
+
 def _ff_small_ok(x, lin1, lin2) -> bool:
-    import os
-    if os.environ.get("KANVIT_NO_FF_SMALL") or not x.is_cuda or x.dtype != torch.float32 or lin1.bias is None or lin2.bias is None:
+    if _lib.py_switches()["no_ff_small"] or not x.is_cuda or x.dtype != torch.float32 or lin1.bias is None or lin2.bias is None:
         return False
-    if os.environ.get("KANVIT_FF", FF_MODE) == "bf16x3":
+    if ff_mode() == "bf16x3":
         return False                       # the opt-in split-product mode was asked for explicitly: it takes the feed-forward
     if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32:
         return False                       # bf16 autocast keeps the stock bf16 GEMMs
     if lin1.weight.dtype != torch.float32 or lin2.out_features != lin1.in_features or lin2.in_features != lin1.out_features:
         return False
-    from . import _lib
     L = _lib.lib()
     return bool(L.kanvit_ff_small_supported(lin1.in_features, lin1.out_features)) and 0 < x.shape[0] <= int(L.kanvit_ff_small_max_rows())
 
@@ -287,10 +294,9 @@ def _ff_small_ok(x, lin1, lin2) -> bool:
 def feed_forward(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear) -> torch.Tensor:
     """lin2(relu(lin1(x))) for a 2-D x: the stock-GEMM path (`dense`) or, when FF_MODE == "bf16x3" and the shapes allow
     it (CUDA, fp32 parameters, widths multiples of 8, biases present, M divisible into slabs), the split-bf16 path."""
-    import os
     if _ff_small_ok(x, lin1, lin2):
         return _FFSmallFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
-    mode = os.environ.get("KANVIT_FF", FF_MODE)
+    mode = ff_mode()
     if (mode == "bf16x3" and x.is_cuda and lin1.bias is not None and lin2.bias is not None and
             lin1.in_features % 8 == 0 and lin1.out_features % 8 == 0 and lin2.out_features % 8 == 0 and
             not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") != torch.float32)):

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from attention import MSA, FlashAttention
 from kanvit import ops
-from kanvit.dense import feed_forward
+from kanvit.dense import feed_forward, ff_small_supported, ln_feed_forward
 from kanvit.ops import add_layernorm
 from models.cheby import ChebyKANLayer
 from models.effkan import KANLinear
@@ -40,8 +40,9 @@ class TransformerBlock(nn.Module):
         (stream after the attention add, this block's feed-forward output) -- same arithmetic as model.py:31-37:
             x = x + MSA(LN1(x));  x = x + FF(LN2(x))."""
         x, h1 = add_layernorm(x, pending, self.norm1)
-        if x.dim() == 3 and x.shape[-1] == 64:       # small geometries: residual add + LN2 + feed-forward in one launch (SURVEY 8(f)1)
-            from kanvit.dense import ln_feed_forward
+        if x.dim() == 3 and ff_small_supported(self.ff[0].in_features, self.ff[0].out_features):
+            # small geometries: residual add + LN2 + feed-forward in one launch (SURVEY 8(f)1); ln_feed_forward itself falls
+            # back to add_layernorm + feed_forward for inputs the fused kernel refuses (dtype, autocast, row count)
             return ln_feed_forward(x, self.attn(h1), self.norm2, self.ff[0], self.ff[2])
         x, h2 = add_layernorm(x, self.attn(h1), self.norm2)
         # Same three ops as self.ff (Linear -> ReLU(inplace) -> Linear, model.py:25-29), applied to the 2-D
@@ -154,7 +155,11 @@ class VisionTransformer(nn.Module):
         lm = self.linear_mapper
         if self._fused_embed is False or isinstance(lm, nn.Linear) or not hasattr(lm, "kan_pack") or hasattr(lm, "kan_u"):
             return None
-        if not images.is_cuda or images.dim() != 4 or torch.is_autocast_enabled("cuda"):
+        # per-call conditions (they depend on the INPUT, so they never touch the cached per-model decision): the kernel wants
+        # contiguous-able fp32 NCHW on the GPU at a 16-byte aligned address, and it produces no gradient for the images --
+        # a caller that differentiates w.r.t. the input (saliency, adversarial examples) takes the three-step path below
+        if (not images.is_cuda or images.dim() != 4 or images.dtype != torch.float32 or images.requires_grad
+                or torch.is_autocast_enabled("cuda") or (images.is_contiguous() and images.data_ptr() % 16)):
             return None
         cfg = lm.kan_cfg()
         w, bp, bias = lm.kan_pack()
@@ -163,7 +168,7 @@ class VisionTransformer(nn.Module):
                                   None if bias is None else bias.reshape(1, -1), self.v_class.reshape(-1),
                                   self.pos_embeddings[: self.n_patches ** 2 + 1], self.n_patches)
         except ops.KanvitError:
-            if self._fused_embed is None:                  # shape not covered: decided once, at the first forward
+            if self._fused_embed is None:                  # layer / geometry not covered: decided once, at the first forward
                 self._fused_embed = False
                 return None
             raise

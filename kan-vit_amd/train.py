@@ -71,7 +71,8 @@ class _GraphedStep:
         torch.cuda.current_stream(x.device).wait_stream(side)
         with torch.no_grad():
             for p, s in zip(model.parameters(), saved):
-                p.copy_(s)
+                if p.requires_grad:             # only what the throw-away step can have changed: rewriting FastKAN's frozen
+                    p.copy_(s)                  # rbf.grid would bump its version and re-derive grid facts (host syncs) in capture
             for st in optimizer.state.values():
                 for v in st.values():
                     if torch.is_tensor(v):
@@ -96,8 +97,15 @@ def main(args, batches=None, init_state=None):
         import torch.distributed as dist
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         local = int(os.environ.get("LOCAL_RANK", rank))
+        # rehearsal hooks for a ONE-GPU box (same as bench.py's; never set by a real launch): every rank on cuda:0, gloo transport
+        if os.environ.get("KANVIT_SHARE_GPU") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("KANVIT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         if args.batch_size % world:
             raise SystemExit(f"--batch-size {args.batch_size} is not divisible by the {world} ranks (equal shards keep the "
                              "all-reduced mean equal to the global-batch mean)")
@@ -171,7 +179,11 @@ def main(args, batches=None, init_state=None):
                 ys.append(y)
                 preds.append(y_hat.argmax(dim=1))
                 probs.append(torch.softmax(y_hat.float(), dim=1))
-        losses = torch.stack(step_losses).cpu() if step_losses else torch.zeros(0)     # the epoch's one host sync
+        losses = torch.stack(step_losses) if step_losses else torch.zeros(0, device=device)
+        if world > 1:                           # every rank's step loss is the mean over ITS shard; equal shards -> the mean
+            torch.distributed.all_reduce(losses)        # of rank means is the global-batch mean the reference would log
+            losses /= world
+        losses = losses.cpu()                   # the epoch's one host sync
         history["losses"] += [float(v) for v in losses]
         train_loss = float(losses.sum() / max(n_batches, 1))
         history["epoch_loss"].append(train_loss)

@@ -124,6 +124,18 @@ def test_switches_are_read_once_and_reported(lib, monkeypatch):
     assert "no_reg=1" in _lib.reload_config()
     monkeypatch.delenv("KANVIT_NO_REG")
     assert _lib.reload_config() == base
+    # the Python-side switches (kanvit/dense.py) follow the same rule and are part of the same report
+    assert "py_ff=default" in base and "py_no_ff_small=0" in base and "py_no_lnff=0" in base
+    monkeypatch.setenv("KANVIT_FF", "bf16x3")
+    monkeypatch.setenv("KANVIT_NO_LNFF", "1")
+    assert _lib.active_config() == base
+    from kanvit import dense
+    assert dense.ff_mode() == "fp32"
+    changed = _lib.reload_config()
+    assert "py_ff=bf16x3" in changed and "py_no_lnff=1" in changed and dense.ff_mode() == "bf16x3"
+    monkeypatch.delenv("KANVIT_FF")
+    monkeypatch.delenv("KANVIT_NO_LNFF")
+    assert _lib.reload_config() == base
     assert "dbg" not in base.lower()                          # the ablation mask of round 1 is gone from the shipped library
 
 

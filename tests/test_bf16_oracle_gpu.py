@@ -238,3 +238,36 @@ def test_vits_fastkan_block_bf16_config2():
     worst = min(report)
     assert worst[0] > 0.99, worst
     assert all(0.95 < r < 1.05 for _, r, _ in report), [x for x in report if not 0.95 < x[1] < 1.05]
+
+
+def test_vitb_mixed_sine_fourier_model_bf16_config4():
+    """BASELINE configs[4] in its own dtype: the two-block type="sine,fourier" ViT-B model (see test_headline_parity_gpu.py's
+    fp32 twin) under bf16 autocast, against oracle.vit_forward in float64 at the loose bounds of the ViT-S FastKAN test above
+    (forward <= 2e-2; gradients by direction and size)."""
+    from model import VisionTransformer
+    torch.manual_seed(11)
+    m = VisionTransformer((3, 224, 224), 14, 2, 768, 12, 100, type="sine,fourier")
+    x = torch.randn(2, 3, 224, 224)
+    labels = torch.tensor([17, 4])
+    params = _params64(m)
+    ref = ko.vit_forward(params, x.double(), 14, 12, "sine")
+    ref_loss = torch.nn.functional.cross_entropy(ref, labels)
+    ref_loss.backward()
+    m = m.to(DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = m(x.to(DEV))
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels.to(DEV))
+    loss.backward()
+    assert 1e-6 < fro(logits.float(), ref.detach()) < 2 * LOOSE, fro(logits.float(), ref.detach())
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-2
+    gmax = max(float(v.grad.norm()) for v in params.values() if v.grad is not None)
+    report = []
+    for k, p in m.named_parameters():
+        g = params[k].grad
+        if g is None or p.grad is None or float(g.norm()) < 1e-3 * gmax:
+            continue
+        a, b = p.grad.detach().double().cpu().flatten(), g.flatten()
+        report.append((float(torch.dot(a, b) / (a.norm() * b.norm())), float(a.norm() / b.norm()), k))
+    worst = min(report)
+    assert worst[0] > 0.99, worst
+    assert all(0.95 < r < 1.05 for _, r, _ in report), [x for x in report if not 0.95 < x[1] < 1.05]

@@ -56,8 +56,14 @@ def test_ff_small_matches_stock_path_and_is_deterministic(monkeypatch):
 
     a, b = run(), run()
     assert all(torch.equal(s, t) for s, t in zip(a, b))          # fixed summation order, no atomics
+    from kanvit import _lib
     monkeypatch.setenv("KANVIT_NO_FF_SMALL", "1")
-    c = run()
+    assert "py_no_ff_small=1" in _lib.reload_config()      # the Python-side switches are read once and echoed like the library's
+    try:
+        c = run()
+    finally:
+        monkeypatch.delenv("KANVIT_NO_FF_SMALL")
+        assert "py_no_ff_small=0" in _lib.reload_config()
     for s, t in zip(a, c):
         assert rel_err(s, t) < 2e-5
 
@@ -141,8 +147,14 @@ def test_block_takes_the_fused_route_and_matches_the_unfused_one(monkeypatch):
 
     fused, tags = run()
     assert "ff_small_fwd" in tags and "ff_small_bwd" in tags
+    from kanvit import _lib
     monkeypatch.setenv("KANVIT_NO_FF_SMALL", "1")
-    plain, tags0 = run()
+    _lib.reload_config()
+    try:
+        plain, tags0 = run()
+    finally:
+        monkeypatch.delenv("KANVIT_NO_FF_SMALL")
+        _lib.reload_config()
     assert "ff_small_fwd" not in tags0
     for a, b in zip(fused, plain):
         assert rel_err(a, b) < 2e-5

@@ -116,3 +116,36 @@ def test_full_geometry_block_vs_fp64_oracle(name):
         g = params[k].grad
         assert g is not None and p.grad is not None, k
         assert close(p.grad.cpu(), g, rtol=TOL, atol=2e-7), (name, k, rel_err(p.grad.cpu(), g, floor=1e-6))
+
+
+def test_mixed_sine_fourier_model_vs_fp64_oracle():
+    """BASELINE configs[4] as a MODEL: ViT-B geometry (224x224, patch 16, N = 197, 12 heads), two blocks, type="sine,fourier"
+    -- block 0 runs SineKAN per-head q|k|v (grid 4), block 1 FourierKAN's (nn.Linear q|k|v, attention.py:136-142), the patch
+    embedding is SineKAN grid 28 (model.split_types; the reference takes one global type, model.py:49,67-80,98-103).  Logits,
+    loss and EVERY gradient (d freq included) against oracle.vit_forward in float64, which dispatches each layer from the
+    state-dict keys."""
+    from model import VisionTransformer
+    torch.manual_seed(11)
+    m = VisionTransformer((3, 224, 224), 14, 2, 768, 12, 100, type="sine,fourier")
+    assert m.block_types == ["sine", "fourier"]
+    x = torch.randn(2, 3, 224, 224)
+    labels = torch.tensor([17, 4])
+    sd = {k: (v.detach().double() if v.is_floating_point() else v) for k, v in m.state_dict().items()}
+    params = {k: v.clone().requires_grad_(not ko.is_buffer_key(k) and v.is_floating_point()) for k, v in sd.items()}
+    assert ko.layer_kind(params, "blocks.0.attn.q_mappings.0.") == "sine" and ko.layer_kind(params, "blocks.1.attn.q_mappings.0.") == "linear"
+    ref = ko.vit_forward(params, x.double(), 14, 12, "sine")
+    ref_loss = torch.nn.functional.cross_entropy(ref, labels)
+    ref_loss.backward()
+    m = m.to(DEV)
+    logits = m(x.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, labels.to(DEV))
+    loss.backward()
+    assert max_err(logits.cpu(), ref) < TOL, max_err(logits.cpu(), ref)
+    assert abs(float(loss) - float(ref_loss)) < TOL
+    seen = set()
+    for k, p in m.named_parameters():
+        g = params[k].grad
+        assert g is not None and p.grad is not None, k
+        assert close(p.grad.cpu(), g, rtol=TOL, atol=2e-7), (k, rel_err(p.grad.cpu(), g, floor=1e-6))
+        seen.add(k.split(".")[-1])
+    assert {"amplitudes", "freq"} <= seen            # SineKAN parameters of block 0 and of the patch embedding were compared

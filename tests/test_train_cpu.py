@@ -1,6 +1,8 @@
 """CPU-only checks of the drop-in's host side: train.py's command line (the reference's flags verbatim, train.py:87-97),
 the reporting helpers against output of the reference's own (tests/golden/metrics.npz, made by make_golden.py from
 utils.py:13-47,79-94), the per-block type extension of BASELINE configs[4], and argument validation."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -83,3 +85,26 @@ def test_attention_rejects_cross_attention_shapes():
         ops._attn_desc(q, torch.randn(1, 2, 5, 16), q, q, False, 0.25)
     with pytest.raises(KanvitError):
         ops._attn_desc(q, q, torch.randn(1, 3, 8, 16), q, False, 0.25)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` invoked PLAINLY (no torch.distributed.run, no RANK): the parent spawns the two ranks as
+    children before touching any GPU, relays rank 0's one JSON line and propagates the exit code.  The --rendezvous-only
+    hook stops each rank after the process group is up (gloo here: no GPU in this container)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KANVIT_DIST_BACKEND="gloo")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                  # ONE line on stdout, whatever the launcher printed
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["sum_of_ones"] == 2.0
+    # a failing rank's exit code comes back through the parent (a backend that does not exist fails inside every CHILD)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=dict(env, KANVIT_DIST_BACKEND="no-such-backend"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "launching" in r.stderr and not r.stdout.strip()

@@ -43,6 +43,34 @@ def test_train_main_reproduces_the_reference_trajectory(t, graph, tmp_path):
     assert abs(float(text.split("Loss: ")[1].split()[0]) - float(np.mean(blob["adam_losses"]))) < 2e-4
 
 
+def test_train_main_graph_with_frozen_parameters_fastkan(tmp_path):
+    """--graph with FastKAN: its rbf.grid is an nn.Parameter with requires_grad=False; the pre-capture restore must not rewrite
+    it (a version bump would re-derive the grid facts with host syncs inside the capture).  Trajectory vs the reference's."""
+    blob, hist = _run("fast", tmp_path, ("--graph",))
+    assert np.allclose(hist["losses"], blob["adam_losses"], atol=1e-4), (hist["losses"], blob["adam_losses"])
+    _, eager = _run("fast", tmp_path)
+    assert eager["losses"] == hist["losses"]                     # eager and replayed steps: bitwise the same
+
+
+def test_train_main_mixed_sine_fourier_eager_graph_and_oracle(tmp_path):
+    """--model-type sine,fourier (BASELINE configs[4]'s mixed blocks) through train.main: eager = --graph bitwise, and both
+    follow the oracle's 3-step Adam trajectory from the same initial state."""
+    import train
+    from model import VisionTransformer
+    from oracle import kan_oracle as ko
+    torch.manual_seed(9)
+    init = {k: v.clone() for k, v in VisionTransformer((1, 28, 28), 7, 2, 64, 2, 10, type="sine,fourier").state_dict().items()}
+    x, y = torch.rand(4, 1, 28, 28), torch.arange(4) % 10
+    want, _ = ko.train_steps(init, x, y, 7, 2, "sine", steps=3)
+    runs = []
+    for extra in ((), ("--graph",)):
+        args = train.parse(["--model-type", "sine,fourier", "--epochs", "1", "--steps-per-epoch", "3", "--log-dir",
+                            str(tmp_path / f"logs{len(runs)}"), "--no-tuned-gemms", *GEOM, *extra])
+        runs.append(train.main(args, batches=[(x, y)] * 3, init_state=init)["losses"])
+    assert runs[0] == runs[1], runs
+    assert np.allclose(runs[0], want, atol=1e-4), (runs[0], want)
+
+
 def test_train_main_bf16_mode_follows_the_reference_loosely(tmp_path):
     blob, hist = _run("cheby", tmp_path, ("--amp", "bf16"))
     assert np.allclose(hist["losses"], blob["adam_losses"], atol=3e-2), (hist["losses"], blob["adam_losses"])
