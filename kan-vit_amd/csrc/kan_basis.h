@@ -205,6 +205,15 @@ __device__ __forceinline__ bool kv_bspline_uniform(const float* __restrict__ kn,
     return true;
 }
 
+// Value of basis jg for a point in knot interval j0 (the four non-zero values v[e] belong to bases j0-3+e).  Written as
+// compares of j0 against CONSTANTS (jg is one after unrolling): the compiler forms each lane mask (j0 == k) once and
+// shares it between the bases -- 11 v_cmp + 4 v_cndmask per basis instead of a 9-instruction select chain per basis.
+// Points outside the knot range carry j0 = KV_BSPLINE_OUT, which matches nothing (every basis 0, models/effkan.py:115).
+constexpr int KV_BSPLINE_OUT = -64;
+__device__ __forceinline__ float kv_bsel4(int j0, int jg, const float (&v)[4]) {
+    return j0 == jg + 3 ? v[0] : (j0 == jg + 2 ? v[1] : (j0 == jg + 1 ? v[2] : (j0 == jg ? v[3] : 0.0f)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: write GP values for feature i (value xv; RBF spline path uses uv) to dst[j*stride]
 // ---------------------------------------------------------------------------------------------
@@ -371,7 +380,7 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
 // conditional, so the compiler cannot speculate the parameter loads (knots, centres, frequencies, phases) out of it; left
 // in the loop they put an L1 round trip on the critical path of every step.
 // ---------------------------------------------------------------------------------------------
-template <int FAM, int GP>
+template <int FAM, int GP, int J0C = -1>      // J0C >= 0: the window start is a compile-time constant (B-spline / RBF windows)
 struct BasisGenP {
     static constexpr int NC0 = (FAM == KV_SINE) ? GP : 1;         // RBF: only the first centre (uniform grid, kv_rbf8)
     static constexpr int NC1 = (FAM == KV_SINE) ? GP : 1;
@@ -426,6 +435,7 @@ struct BasisGenP {
             const float fl = floorf(tt);
             j0 = (int)fl;
             in = (tt >= 0.0f) && (j0 < nkm1);
+            if (!in) j0 = KV_BSPLINE_OUT;
             const float uu = tt - fl, u2 = uu * uu, u3 = u2 * uu, om = 1.0f - uu;
             const float s6 = 1.0f / 6.0f;
             bv[0] = om * om * om * s6;
@@ -445,14 +455,13 @@ struct BasisGenP {
             p1 = p2;
             return p2;
         } else if constexpr (FAM == KV_BSPLINE) {
-            const int jg = j0w + j;
+            const int jg = (J0C >= 0 ? J0C : j0w) + j;
             if (jg >= G) return kv_silu(x);
-            const int e = jg - (j0 - 3);
-            const float v = e == 0 ? bv[0] : (e == 1 ? bv[1] : (e == 2 ? bv[2] : bv[3]));
-            return (in && e >= 0 && e < 4) ? v : 0.0f;
+            return kv_bsel4(j0, jg, bv);
         } else if constexpr (FAM == KV_RBF) {
-            if (j0w + j >= G) return kv_silu(x);
-            return kv_sel8(pr, j);
+            const int jg = (J0C >= 0 ? J0C : j0w) + j;
+            if (jg >= G) return kv_silu(x);
+            return kv_sel8(pr, jg);            // compile-time jg: the unused Gaussians of a window are never computed (dead code)
         } else if constexpr (FAM == KV_FOURIER) {
             const float v = sin_half ? sk : ck;
             const float cn = ck * c1r - sk * s1;
@@ -518,6 +527,7 @@ struct BasisGen {
         } else if constexpr (FAM == KV_BSPLINE) {
             float dv[4];
             in = kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, false);     // uniform knots only (host-checked)
+            if (!in) j0 = KV_BSPLINE_OUT;
         } else if constexpr (FAM == KV_FOURIER) {
             kv_sincos(xv, s1, c1);
             ck = c1;
@@ -536,9 +546,7 @@ struct BasisGen {
             return p2;
         } else if constexpr (FAM == KV_BSPLINE) {
             if (j >= G) return kv_silu(x);
-            const int e = j - (j0 - 3);
-            const float v = e == 0 ? bv[0] : (e == 1 ? bv[1] : (e == 2 ? bv[2] : bv[3]));
-            return (in && e >= 0 && e < 4) ? v : 0.0f;
+            return kv_bsel4(j0, j, bv);
         } else if constexpr (FAM == KV_RBF) {
             if (j >= G) return kv_silu(x);
             return kv_sel8(pr, j);
@@ -590,6 +598,7 @@ struct BasisDGen {
         } else if constexpr (FAM == KV_BSPLINE) {
             float bv[4];
             in = kv_bspline_uniform(b.bp, b.nk, xv, j0, bv, dv, true);
+            if (!in) j0 = KV_BSPLINE_OUT;
         } else if constexpr (FAM == KV_FOURIER) {
             kv_sincos(xv, s1, c1);
             ck = c1;
@@ -609,9 +618,7 @@ struct BasisDGen {
             return r;
         } else if constexpr (FAM == KV_BSPLINE) {
             if (j >= G) return kv_dsilu(x);
-            const int e = j - (j0 - 3);
-            const float v = e == 0 ? dv[0] : (e == 1 ? dv[1] : (e == 2 ? dv[2] : dv[3]));
-            return (in && e >= 0 && e < 4) ? v : 0.0f;
+            return kv_bsel4(j0, j, dv);
         } else if constexpr (FAM == KV_RBF) {
             if (j >= G) return kv_dsilu(x);
             return kv_sel8(pr, j) * (-2.0f * (t - (float)j) * inv_h);

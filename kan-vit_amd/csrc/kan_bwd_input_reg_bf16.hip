@@ -1,0 +1,337 @@
+// Register-form input gradient on the bf16 matrix cores (split out of kan_layer.hip; see kan_layer_common.h).
+#include "kan_layer_common.h"
+
+namespace {
+
+// =============================================================================================
+// backward w.r.t. the input, register form on the bf16 matrix cores.  Same slot <-> (feature, basis) permutation and
+// in-register chain rule as kan_bwd_input_reg_kernel; the contraction over the dY columns uses v_mfma_f32_32x32x16_bf16:
+// k-step ks covers 16 columns, lane half h the 8 columns 16*ks + 8*h .. +7 -- the B fragment is 8 consecutive dY values
+// of the lane's own row (registers, rounded to bf16), the A fragment one ds_read_b128 from the repacked image
+// [chunk][ks][h][k row][8 n] (kan_pack_w_bwd_reg_kernel).  One step = all O columns of one group: T = nci * nshare steps.
+// Requirements: as the fp32 register kernel, plus O in {32, 64}.
+// =============================================================================================
+// wb2[g][nci][O/16][2][KCT][8]: element (ks, h, kr, e) = w[g][k(kr)][16*ks + 8*h + e], k(kr) by the slot permutation
+// (ldw, gstride): row stride of w and the offset between two "groups" -- (O, K*O) for real groups, (O_real, 64) when the groups
+// are the 64-column chunks of one wide layer
+__global__ __launch_bounds__(256) void kan_pack_w_bwd_reg_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb2,
+                                                                 int K, int O, int GP, int FPH, int KCT, int nci, long long total,
+                                                                 long long ldw, long long gstride) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (g, ci, ks, h, kr) per thread
+    if (e >= total) return;
+    const int kr = (int)(e % KCT);
+    long long r = e / KCT;
+    const int h = (int)(r & 1);
+    r >>= 1;
+    const int ks = (int)(r % (O / 16));
+    r /= (O / 16);
+    const int ci = (int)(r % nci);
+    const long long g = r / nci;
+    const int rho = kr & 31, kt = kr >> 5;
+    const int h_ = (rho >> 2) & 1, r_ = (rho & 3) + 4 * (rho >> 3);
+    const int slot = kt * 16 + r_;
+    const int jq = slot / GP, g_ = slot - jq * GP;
+    const int k = (ci * 2 * FPH + h_ * FPH + jq) * GP + g_;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (jq < FPH && k < K) ? w[g * gstride + (long long)k * ldw + 16 * ks + 8 * h + j] : 0.0f;
+    u32x4 out = {kv_pack_bf16(v[0], v[1]), kv_pack_bf16(v[2], v[3]), kv_pack_bf16(v[4], v[5]), kv_pack_bf16(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(wb2 + e * 8) = out;
+}
+
+template <int FAM, int GP, int KT, bool SHARED>
+__global__ __launch_bounds__(256, FAM == KV_SINE ? 1 : 2) void kan_bwd_input_reg_bf16_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KCT = 32 * KT;
+    constexpr int FPH = (16 * KT) / GP;
+    constexpr int IC = 2 * FPH;
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr bool SINE = (FAM == KV_SINE);
+    constexpr int MAXKS = 4;                      // O <= 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int gx = blockIdx.x;
+    const long long m0 = (long long)blockIdx.y * BM;
+    const int nshare = a.groups / a.xmod;
+    const int nci = a.I / IC, nks = a.O / 16;
+    const int mrem = (m0 + BM <= a.M) ? BM : (int)(a.M - m0);
+    const int row = wave * 32 + l31;
+    const bool row_ok = row < mrem;
+    const long long grow = m0 + (row_ok ? row : 0);
+    unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [2][nks][2][KCT][8]
+    const int WSZ = nks * 2 * KCT * 8;            // bf16 elements per buffer
+    const int NV = nks * 2 * KCT;                 // 16-byte vectors per buffer
+    // SINE: [real groups sharing x][4 waves][GP] partial d loss / d freq of this row tile (as the fp32 register kernel)
+    const int ndf = a.vcols ? 1 : nshare;
+    float* dfq_s = reinterpret_cast<float*>(W_s + 2 * (size_t)WSZ);
+    if constexpr (SINE) {
+        for (int j = tid; j < ndf * 4 * GP; j += 256) dfq_s[j] = 0.0f;
+    }
+
+    const float* xrow = a.x + grow * a.ldx + (long long)gx * a.I + hf * FPH;
+    float* dxrow = a.dx + grow * a.ldx + (long long)gx * a.I + hf * FPH;
+    const float* dyrow = a.dy + grow * a.ldy + hf * 8;
+
+    constexpr int WQ = (MAXKS * 2 * KCT + 255) / 256;
+    u32x4 wreg[WQ];
+    auto load_w = [&](int ci, int g) {
+        const unsigned short* src = a.wb2 + (((long long)g * nci + ci) * NV) * 8;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int v = tid + q * 256;
+            if (v < NV) wreg[q] = *reinterpret_cast<const u32x4*>(src + (long long)v * 8);
+        }
+    };
+    auto store_w = [&](int buf) {
+        unsigned short* dst = W_s + (size_t)buf * WSZ;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int v = tid + q * 256;
+            if (v < NV) *reinterpret_cast<u32x4*>(dst + (size_t)v * 8) = wreg[q];
+        }
+    };
+    f32x4 dyreg[MAXKS][2];
+    auto load_dy = [&](int g) {
+        const float* src = dyrow + (long long)g * a.O;
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks)
+            if (ks < nks) {
+                dyreg[ks][0] = *reinterpret_cast<const f32x4*>(src + 16 * ks);
+                dyreg[ks][1] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+            }
+    };
+
+    const int T = nci * nshare;
+    f32x16 acc[KT];
+    float dxacc[FPH];
+    float xv[FPH];
+
+    int ci = 0, p = 0;
+    load_w(0, gx);
+    load_dy(gx);
+    store_w(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (p == 0) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < FPH; ++j) dxacc[j] = 0.0f;
+            if constexpr (FPH % 4 == 0) {
+#pragma unroll
+                for (int j4 = 0; j4 < FPH / 4; ++j4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + ci * IC + 4 * j4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[4 * j4 + e] = v[e];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < FPH; ++j) xv[j] = xrow[ci * IC + j];
+            }
+        }
+        bf16x8_t dyb[MAXKS];
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) {
+            const u32x4 u = {kv_pack_bf16(dyreg[ks][0][0], dyreg[ks][0][1]), kv_pack_bf16(dyreg[ks][0][2], dyreg[ks][0][3]),
+                             kv_pack_bf16(dyreg[ks][1][0], dyreg[ks][1][1]), kv_pack_bf16(dyreg[ks][1][2], dyreg[ks][1][3])};
+            dyb[ks] = __builtin_bit_cast(bf16x8_t, u);
+        }
+        int cin = ci, pn = p + 1;
+        if (pn == nshare) { pn = 0; ++cin; }
+        if (t + 1 < T) {
+            load_w(cin, pn * a.xmod + gx);
+            load_dy(pn * a.xmod + gx);
+        }
+        const unsigned short* wp = W_s + (size_t)(t & 1) * WSZ + ((size_t)hf * KCT + l31) * 8;
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks)
+            if (ks < nks) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)(2 * ks) * KCT + kt * 32) * 8);
+                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, dyb[ks], acc[kt], 0, 0, 0);
+                }
+            }
+        const bool ends = SHARED ? (p == nshare - 1) : true;
+        if (ends) {
+            const int g = a.vcols ? gx : p * a.xmod + gx;      // column chunks of one wide layer: ONE real group
+            const BasisArgs b = make_basis(a, g);
+            float duv[RBF ? FPH : 1];
+            float uvv[RBF ? FPH : 1];
+            if constexpr (RBF) {
+                if (a.ln) {                       // KANVIT_FLAG_FUSED_LN: u from x, the saved row statistics and this group's gamma / beta
+                    const float2 st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
+                    const float* gb = b.bp + a.G + ci * IC + hf * FPH;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) uvv[j] = (xv[j] - st.x) * st.y * gb[j] + gb[a.I + j];
+                } else {
+                    const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
+                }
+            }
+            float dfq[SINE ? GP : 1];
+            if constexpr (SINE) {
+#pragma unroll
+                for (int g_ = 0; g_ < GP; ++g_) dfq[g_] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < FPH; ++j) {
+                BasisDGen<FAM> gen;
+                gen.init(b, xv[j], RBF ? uvv[j] : 0.0f, ci * IC + hf * FPH + j);
+                float dsum = 0.0f, usum = 0.0f;
+#pragma unroll
+                for (int g_ = 0; g_ < GP; ++g_) {
+                    const int slot = j * GP + g_;
+                    const float d = gen.next(g_);
+                    const float v = acc[slot / 16][slot % 16];
+                    if (RBF && g_ < GP - 1) usum += v * d;
+                    else dsum += v * d;
+                    if constexpr (SINE) dfq[g_] += v * gen.lastc * xv[j];
+                }
+                dxacc[j] += dsum;
+                if constexpr (RBF) duv[j] = usum;
+            }
+            if constexpr (SINE) {                 // one wave reduction per grid point and step; rows past M contribute nothing
+                const int pg = a.vcols ? 0 : p;
+#pragma unroll
+                for (int g_ = 0; g_ < GP; ++g_) {
+                    const float part = kv_wave_sum(row_ok ? dfq[g_] : 0.0f);
+                    if (lane == 0) dfq_s[(pg * 4 + wave) * GP + g_] += part;
+                }
+            }
+            if constexpr (RBF) {
+                if (a.du && row_ok) {
+                    float* durow = a.du + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) durow[j] = duv[j];
+                }
+            }
+            if (p == nshare - 1 && row_ok) {
+                if constexpr (FPH % 4 == 0) {
+#pragma unroll
+                    for (int j4 = 0; j4 < FPH / 4; ++j4) {
+                        const f32x4 v = {dxacc[4 * j4], dxacc[4 * j4 + 1], dxacc[4 * j4 + 2], dxacc[4 * j4 + 3]};
+                        *reinterpret_cast<f32x4*>(dxrow + ci * IC + 4 * j4) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) dxrow[ci * IC + j] = dxacc[j];
+                }
+            }
+            if (!SHARED || p == nshare - 1) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
+            }
+        }
+        if (t + 1 < T) store_w((t + 1) & 1);
+        __syncthreads();
+        ci = cin; p = pn;
+    }
+    if constexpr (SINE) {                         // combine the 4 waves in a fixed order (the last loop barrier orders the adds)
+        const int rgroups = a.vcols ? 1 : a.groups;
+        for (int j = tid; j < ndf * GP; j += 256) {
+            const int pp = j / GP, gg = j - pp * GP;
+            const float* src = dfq_s + (pp * 4) * GP + gg;
+            const float v = ((src[0] + src[GP]) + src[2 * GP]) + src[3 * GP];
+            a.dparam[((long long)blockIdx.y * rgroups + (a.vcols ? 0 : pp * a.xmod + gx)) * a.G + gg] = v;
+        }
+    }
+}
+
+template <int FAM, int GP, int KT>
+int launch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t st) {
+    const long long total = (long long)a.groups * p.nci * (a.O / 16) * 2 * 32 * KT;
+    if (p.vcols) {
+        // one wide layer (the patch embedding: O = 384 / 768): its 64-column chunks are contracted one per step into the SAME
+        // accumulators -- exactly the SHARED schedule with the chunks in the role of the groups that share x and the basis
+        hipLaunchKernelGGL(kan_pack_w_bwd_reg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w,
+                           const_cast<unsigned short*>(a.wb2), a.K, 64, GP, p.fph, 32 * KT, p.nci, total, (long long)a.O, 64LL);
+        KV_LAUNCH_CHECK("kan_pack_w_bwd_reg_kernel");
+        LayerArgs v = a;
+        v.groups = p.vcols;
+        v.xmod = 1;
+        v.O = 64;
+        v.vcols = 1;
+        dim3 vgrid(1, (unsigned)((a.M + BM - 1) / BM), 1);
+        hipLaunchKernelGGL((kan_bwd_input_reg_bf16_kernel<FAM, GP, KT, true>), vgrid, dim3(256), p.lds, st, v);
+        KV_LAUNCH_CHECK("kan_bwd_input_reg_bf16_kernel");
+        return 0;
+    }
+    hipLaunchKernelGGL(kan_pack_w_bwd_reg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.w,
+                       const_cast<unsigned short*>(a.wb2), a.K, a.O, GP, p.fph, 32 * KT, p.nci, total, (long long)a.O, (long long)a.K * a.O);
+    KV_LAUNCH_CHECK("kan_pack_w_bwd_reg_kernel");
+    const int nshare = a.groups / a.xmod;
+    const bool shared = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare > 1;
+    dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
+    if (shared) {
+        if constexpr (kv_shared_basis<FAM>()) {
+            hipLaunchKernelGGL((kan_bwd_input_reg_bf16_kernel<FAM, GP, KT, true>), grid, dim3(256), p.lds, st, a);
+            KV_LAUNCH_CHECK("kan_bwd_input_reg_bf16_kernel");
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((kan_bwd_input_reg_bf16_kernel<FAM, GP, KT, false>), grid, dim3(256), p.lds, st, a);
+    KV_LAUNCH_CHECK("kan_bwd_input_reg_bf16_kernel");
+    return 0;
+}
+
+template <int FAM>
+int dispatch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t st) {
+    if constexpr (FAM == KV_LINEAR) return launch_bwd_input_reg_bf16<FAM, 1, 2>(a, p, st);
+    if constexpr (FAM == KV_CHEBY) return launch_bwd_input_reg_bf16<FAM, 5, 5>(a, p, st);
+    if constexpr (FAM == KV_BSPLINE) return launch_bwd_input_reg_bf16<FAM, 9, 5>(a, p, st);
+    if constexpr (FAM == KV_RBF) return launch_bwd_input_reg_bf16<FAM, 9, 5>(a, p, st);
+    if constexpr (FAM == KV_SINE) {
+        if (!a.dparam) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: SINE needs dparam");
+        return p.gp == 28 ? launch_bwd_input_reg_bf16<FAM, 28, 7>(a, p, st) : launch_bwd_input_reg_bf16<FAM, 4, 4>(a, p, st);
+    }
+    return kv_fail(KANVIT_EINVAL, "internal: bf16 register input-gradient dispatch");
+}
+
+
+}  // namespace
+
+BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
+    BwdRegBf16Plan p{};
+    if (kv_config().no_reg || kv_config().no_bf16 || !(d->flags & KANVIT_FLAG_BF16_MFMA)) return p;
+    p.gp = gp_of(d);
+    const int fam = d->family;
+    if (fam == KANVIT_LINEAR && p.gp == 1) p.kt = 2;
+    else if (fam == KANVIT_CHEBY && p.gp == 5) p.kt = 5;
+    else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) p.kt = 5;
+    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.kt = 5;
+    else if (fam == KANVIT_SINE && p.gp == 4) p.kt = 4;        // the per-head mappings (attention.py:140)
+    else if (fam == KANVIT_SINE && p.gp == 28) p.kt = 7;       // the G = 28 patch embedding (model.py:72)
+    else return p;
+    p.fph = 16 * p.kt / p.gp;
+    const int ic = 2 * p.fph;
+    const bool wide = d->groups == 1 && d->x_group_mod == 1 && d->O > 64 && d->O % 64 == 0 && d->O <= 64 * 64;
+    if (d->I % ic || !(d->O == 32 || d->O == 64 || wide)) return p;
+    if ((d->ldx & 3) || (d->ldy & 3) || (d->I & 3) || (fam == KANVIT_RBF && (d->ldu & 3))) return p;
+    p.nci = d->I / ic;
+    p.vcols = wide ? d->O / 64 : 0;
+    const int oc = wide ? 64 : d->O;                 // columns per step
+    p.lds = (size_t)2 * (oc / 16) * 2 * 32 * p.kt * 16;
+    if (fam == KANVIT_SINE) p.lds += sizeof(float) * (size_t)(wide ? 1 : d->groups / d->x_group_mod) * 4 * p.gp;
+    p.ws_bytes = (size_t)d->groups * p.nci * (d->O / 16) * 2 * 32 * p.kt * 16;
+    p.ok = true;
+    return p;
+}
+
+bool bwd_input_bf16_ok(const kanvit_layer_desc* d) {
+    const bool wide = d->groups == 1 && d->x_group_mod == 1 && d->O > 64 && d->O % 64 == 0 && d->O <= 64 * 64;      // register kernel only
+    // SINE has no bf16 register kernel (its d loss / d freq partials), and the bf16 LDS-tile kernel measures SLOWER than the exact
+    // fp32 register kernel (0.81 vs 0.38 ms on the ViT-B q|k|v launch): the flag allows bf16, it does not require it
+    if (d->family == KANVIT_SINE && !kv_config().no_reg && !plan_bwd_input_reg_bf16(d).ok) return false;
+    return (d->flags & KANVIT_FLAG_BF16_MFMA) && (d->O == 16 || d->O == 32 || d->O == 64 || wide) && (d->ldy % 4 == 0) && !kv_config().no_bf16;
+}
+
+int kv_bwd_input_reg_bf16(int family, LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t st) {
+#define KV_CALL(F) dispatch_bwd_input_reg_bf16<F>(a, p, st)
+    KV_FAMILY_SWITCH(family, KV_CALL)
+#undef KV_CALL
+}

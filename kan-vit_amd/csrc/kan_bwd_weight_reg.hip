@@ -1,0 +1,365 @@
+// Streaming register-form weight gradient + the ordered slab reduction (split out of kan_layer.hip; see kan_layer_common.h).
+#include "kan_layer_common.h"
+
+namespace {
+
+// =============================================================================================
+// backward w.r.t. the weights, register form: a barrier-free, LDS-free streaming kernel.
+//   dW[g][i*GP + j][o] = sum_m Phi_j(x[m][i]) * dY[m][g*O + o]
+// The contraction runs over tokens, so the MFMA lane index of the Phi operand is the K row.  K is tiled so that k-tile j of
+// a 32-feature block holds basis function j of 32 DIFFERENT features: lane (l & 31) owns one feature, evaluates its GP
+// basis functions at its token(s) once (BasisGen, a recurrence for Chebyshev) and those GP values ARE its A fragments of
+// the GP k-tiles.  The dY operand is a plain dword load (lane = output column).  Each wave accumulates a
+// [32 features x GP] x [NOT column tiles] block of dW in registers (GP*NOT*16 accumulators) over its slab of tokens;
+// operands are software-prefetched PD blocks ahead (one wave per SIMD: latency is hidden by the prefetch, not occupancy).
+// Work-group = 4 consecutive wave units (feature block fastest), so neighbouring waves share dY (and x across tile sets).
+// fp32: v_mfma_f32_32x32x2f32, 2 tokens per step (lane half = token parity).  bf16 flag: v_mfma_f32_32x32x16_bf16, 16
+// tokens per step, lane half h owns tokens 8h..8h+7 of the step.  Rows beyond the slab end are clamped for x and zeroed
+// for dY.  Partials go to slab[s][g][k][o]; kan_slab_reduce_kernel sums them in order.
+// grid ceil(units * slabs / 4), 256 threads = 4 (slab, wave unit) pairs, unit fastest.
+// =============================================================================================
+template <int FAM, int GP, int NOT, bool BF, int JC = GP>
+__global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
+                                                                 int shared, int nbg) {
+    constexpr int NJC = GP / JC;                  // wide bases (G = 28) are contracted in NJC windows of JC basis functions,
+                                                  // each its own wave unit (every window regenerates only its own values)
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr int TS = BF ? 8 : 1;            // tokens per lane per step
+    constexpr bool BIG = !BF && JC * NOT >= 18 && NOT >= 6;   // 288 accumulators x six dY streams: room for three blocks of two steps, not two of four
+    constexpr int UB = BF ? 1 : (BIG ? 2 : 4);        // steps per prefetch block
+    constexpr int PD = (BF || BIG) ? 3 : 2;           // blocks in flight
+    constexpr int NTOK = TS * UB;             // tokens per lane per block
+    // the wave index is uniform by construction; telling the compiler (readfirstlane) keeps everything derived from it -- unit
+    // and slab numbers, tile columns, the slab's base pointers -- in scalar registers instead of one vector register each
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hf = lane >> 5;
+    // wave unit u = (basis group, column-tile set, feature block), feature block fastest: the 4 waves of a work-group are
+    // always 4 live units (a partly populated work-group would leave SIMDs idle: one wave fills a SIMD's register file,
+    // so the next work-group cannot start until ALL four SIMDs are free)
+    const int units = nfb * nos * nbg * NJC;
+    const long long gw = (long long)blockIdx.x * 4 + wave;       // global wave index over (slab, unit), unit fastest
+    if (gw >= (long long)units * a.msplit) return;
+    const int u = (int)(gw % units), slab = (int)(gw / units);
+    const int fb = u % nfb, os = (u / nfb) % nos, jc = (u / (nfb * nos)) % NJC, bg = u / (nfb * nos * NJC);
+    const int j0 = jc * JC;
+    const long long ms = (long long)slab * a.rows_per_split;
+    long long me = ms + a.rows_per_split;
+    if (me > a.M) me = a.M;
+    const int len = (int)(me - ms);
+    if (len <= 0) return;
+    const int otpg = a.O / 32;
+    const int f = fb * 32 + l31;
+    const int gx = bg % a.xmod;
+
+    // this wave's column tiles
+    int tg[NOT];          // group of tile i (or -1)
+    long long tcol[NOT];  // column offset of tile i in a dY row
+#pragma unroll
+    for (int i = 0; i < NOT; ++i) {
+        const int tt = os * NOT + i;
+        if (tt < tiles_per_bg) {
+            const int p = tt / otpg;
+            tg[i] = shared ? p * a.xmod + bg : bg;
+            tcol[i] = (long long)tg[i] * a.O + (tt - p * otpg) * 32;
+        } else {            // past the last tile: recompute the first tile (no branch around the MFMAs), never stored
+            tg[i] = -1;
+            tcol[i] = (long long)(shared ? ((os * NOT) / otpg) * a.xmod + bg : bg) * a.O + ((os * NOT) % otpg) * 32;
+        }
+    }
+    // B-spline / FastKAN windows (GP = 9 contracted as three windows of three basis functions, each its own wave unit): the
+    // window start is made a COMPILE-TIME constant by a wave-uniform switch over three copies of the body -- the selection of
+    // a window's values (kv_bsel4 lane masks, kv_sel8) then folds, and the Gaussians / spline pieces the window does not need
+    // are never computed.  Every other instantiation runs the body once with the run-time window start j0.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto run = [&](auto j0c) {
+    constexpr int J0C = decltype(j0c)::value;
+    const int g0 = bg;                 // basis parameters: identical for every group of a shared launch
+    const BasisArgs b = make_basis(a, g0);
+    BasisGenP<FAM, JC, J0C> proto;          // knots / centres / frequencies / phases of this lane's feature, loaded once
+    proto.prepare(b, f, j0);
+
+    // Addressing: wave-uniform 64-bit bases (start of this slab) + 32-bit per-lane offsets, so that a load costs one or two
+    // VALU instructions for its address instead of a 64-bit multiply-add chain: the PMC pass of round 1 counted 3.5 VALU
+    // instructions per MFMA in this kernel, mostly address arithmetic, and the fp32 matrix pipe waits for every one of them
+    // (DESIGN.md section 4.1).  The host guarantees rows_per_split * max(ldx, ldu, ldy) < 2^29 elements.
+    const float* xbase = a.x + ms * a.ldx + (long long)gx * a.I;                                  // uniform
+    const float* ubase = RBF ? (a.u ? a.u + ms * a.ldu + (long long)g0 * a.I : xbase) : xbase;      // uniform
+    const int ldx32 = (int)a.ldx, ldu32 = RBF ? (a.u ? (int)a.ldu : (int)a.ldx) : (int)a.ldx, ldy32 = (int)a.ldy;
+    const float* dybase = a.dy + ms * a.ldy;                                                        // uniform
+    int dyo[NOT];
+#pragma unroll
+    for (int i = 0; i < NOT; ++i) dyo[i] = (int)tcol[i] + l31;
+
+    f32x16 acc[JC][NOT];
+#pragma unroll
+    for (int j = 0; j < JC; ++j)
+#pragma unroll
+        for (int i = 0; i < NOT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+    // token of (block, step u, e): fp32: 2*(blk*UB + u) + hf ; bf16: 16*blk + 8*hf + e
+    float rx[PD][NTOK], ru[RBF ? PD : 1][RBF ? NTOK : 1], rdy[PD][NTOK][NOT];
+    // KANVIT_FLAG_FUSED_LN: u = (x - mean) * rstd * gamma + beta is formed when a block leaves the ring.  The slab's (mean, rstd)
+    // pairs sit in a wave-private LDS strip (the register file is full: a second ring for them spills), filled once up front
+    // and read back as two-address broadcasts; no barrier -- the strip belongs to this wave alone.
+    const bool ln = RBF && a.ln;
+    float ln_g = 1.0f, ln_b = 0.0f;               // gamma / beta of this lane's feature
+    const float2* st_w = nullptr;
+    if constexpr (RBF) {
+        if (ln) {
+            ln_g = b.bp[a.G + f];
+            ln_b = b.bp[a.G + a.I + f];
+            float2* strip = reinterpret_cast<float2*>(smem) + (size_t)wave * a.rows_per_split;
+            const float* stbase = a.stats + (ms * a.xmod + gx) * 2;      // uniform
+            for (int i = lane; i < len; i += 64) strip[i] = *reinterpret_cast<const float2*>(stbase + (size_t)i * (2 * a.xmod));
+            st_w = strip;
+        }
+    }
+    auto tok_of = [&](int blk, int t) -> int { return BF ? (16 * blk + 8 * hf + t) : (2 * (blk * UB + t) + hf); };
+    auto load_block = [&](int q, int blk) {
+#pragma unroll
+        for (int t = 0; t < NTOK; ++t) {
+            int tk = tok_of(blk, t);
+            if (tk > len - 1) tk = len - 1;
+            rx[q][t] = xbase[tk * ldx32 + f];
+            if constexpr (RBF) {
+                if (!ln) ru[q][t] = ubase[tk * ldu32 + f];
+            }
+            const int dyr = tk * ldy32;
+#pragma unroll
+            for (int i = 0; i < NOT; ++i) rdy[q][t][i] = dybase[dyr + dyo[i]];
+        }
+    };
+    const int tok_per_blk = BF ? 16 : 2 * UB;
+    const int nblk = (len + tok_per_blk - 1) / tok_per_blk;
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+        if (q < nblk) load_block(q, q);
+
+    for (int blk0 = 0; blk0 < nblk; blk0 += PD) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            const int blk = blk0 + q;
+            if (blk < nblk) {
+                // take the block out of the ring (this is where the loads are waited for), zero dY of rows past the slab
+                float cx[NTOK], cu[RBF ? NTOK : 1], cdy[NTOK][NOT];
+#pragma unroll
+                for (int t = 0; t < NTOK; ++t) {
+                    const bool ok = tok_of(blk, t) < len;
+                    cx[t] = rx[q][t];
+                    if constexpr (RBF) {
+                        if (ln) {
+                            const int tk = tok_of(blk, t);
+                            const float2 st = st_w[tk < len ? tk : len - 1];
+                            cu[t] = (rx[q][t] - st.x) * st.y * ln_g + ln_b;
+                        } else {
+                            cu[t] = ru[q][t];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NOT; ++i) cdy[t][i] = ok ? rdy[q][t][i] : 0.0f;
+                }
+                if (blk + PD < nblk) load_block(q, blk + PD);
+                if constexpr (!BF) {
+#pragma unroll
+                    for (int t = 0; t < NTOK; ++t) {
+                        BasisGenP<FAM, JC, J0C> gen = proto;
+                        gen.init(cx[t], RBF ? cu[t] : 0.0f);
+#pragma unroll
+                        for (int j = 0; j < JC; ++j) {
+                            const float av = gen.next(j);
+#pragma unroll
+                            for (int i = 0; i < NOT; ++i)
+                                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    unsigned af[JC][4];
+#pragma unroll
+                    for (int ep = 0; ep < 4; ++ep) {
+                        BasisGenP<FAM, JC, J0C> g0_ = proto, g1_ = proto;
+                        g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
+                        g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
+#pragma unroll
+                        for (int j = 0; j < JC; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
+                    }
+                    bf16x8_t bfr[NOT];
+#pragma unroll
+                    for (int i = 0; i < NOT; ++i) {
+                        const u32x4 u4 = {kv_pack_bf16(cdy[0][i], cdy[1][i]), kv_pack_bf16(cdy[2][i], cdy[3][i]),
+                                          kv_pack_bf16(cdy[4][i], cdy[5][i]), kv_pack_bf16(cdy[6][i], cdy[7][i])};
+                        bfr[i] = __builtin_bit_cast(bf16x8_t, u4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < JC; ++j) {
+                        const u32x4 a4 = {af[j][0], af[j][1], af[j][2], af[j][3]};
+                        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, a4);
+#pragma unroll
+                        for (int i = 0; i < NOT; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[i], acc[j][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // dW partial of this slab: row k = (fb*32 + acc row)*GP + j, 32 contiguous columns per row
+    float* base = a.slab + (long long)slab * ((long long)a.groups * a.K * a.O);
+#pragma unroll
+    for (int i = 0; i < NOT; ++i) {
+        if (tg[i] < 0) continue;
+        const int tt = os * NOT + i;
+        const int col0 = (tt % otpg) * 32;
+        float* gb = base + (long long)tg[i] * a.K * a.O + col0 + l31;
+#pragma unroll
+        for (int j = 0; j < JC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int fr = fb * 32 + kv_acc_row(r, hf);
+                gb[((long long)fr * GP + j0 + j) * a.O] = acc[j][i][r];
+            }
+    }
+    };
+    if constexpr ((FAM == KV_BSPLINE || FAM == KV_RBF) && NJC > 1) {
+        static_assert(NJC <= 3, "window switch covers three windows");
+        if (jc == 0) run(std::integral_constant<int, 0>{});
+        else if (jc == 1) run(std::integral_constant<int, JC>{});
+        else run(std::integral_constant<int, 2 * JC>{});
+    } else {
+        run(std::integral_constant<int, -1>{});
+    }
+}
+
+// ordered sum of the msplit partial slabs (deterministic; no float atomics)
+__global__ __launch_bounds__(256) void kan_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                              long long total, int msplit) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        float s = slab[e];
+        int ms = 1;
+        for (; ms + 7 < msplit; ms += 8) {            // eight loads in flight, added in slab order
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = slab[(long long)(ms + j) * total + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += t[j];
+        }
+        for (; ms < msplit; ++ms) s += slab[(long long)ms * total + e];
+        dw[e] = s;
+    }
+}
+
+template <int FAM, int GP, int NOT, int JC = GP, bool HAS_BF = true>
+int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+    const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
+    dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
+    const size_t lds = a.ln ? (size_t)4 * p.rows_per_slab * sizeof(float2) : 0;      // four wave-private (mean, rstd) strips
+    if constexpr (HAS_BF) {
+        if (bf) {
+            if (lds > 64 * 1024) KV_ALLOW_LDS(160 * 1024, (kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>));
+            hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>), grid, dim3(256), lds, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+            KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
+            return 0;
+        }
+    } else if (bf) {
+        return kv_fail(KANVIT_EINVAL, "internal: this register weight-gradient instantiation has no bf16 form");
+    }
+    {
+        if (lds > 64 * 1024) KV_ALLOW_LDS(160 * 1024, (kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>));
+        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>), grid, dim3(256), lds, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+    }
+    KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
+    return 0;
+}
+
+int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+    switch (family) {
+        case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
+        case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
+        case KANVIT_BSPLINE:      // exact fp32 only (the plan refuses bf16 mode: there the LDS-tile bf16 kernel runs)
+            return p.nt == 6 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 6, 3, false>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 3, false>(a, p, bf, st);
+        case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
+        case KANVIT_SINE:
+            if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE, 28, 4, 4>(a, p, bf, st);
+            return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE, 5, 2>(a, p, bf, st);
+        case KANVIT_FOURIER: return launch_bwd_weight_reg<KV_FOURIER, 56, 4, 4>(a, p, bf, st);
+        default: return kv_fail(KANVIT_EINVAL, "internal: register weight-gradient dispatch");
+    }
+}
+
+
+}  // namespace
+
+BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
+    BwRegPlan p{};
+    if (kv_config().no_reg || kv_config().no_reg_bw) return p;
+    p.njc = 1;
+    p.gp = gp_of(d);
+    const int fam = d->family;
+    if (fam == KANVIT_LINEAR && p.gp == 1) p.nt = 6;
+    else if (fam == KANVIT_CHEBY && p.gp == 5) p.nt = 3;
+    // BSPLINE (GP = 9: 8 cubic bases + silu): three windows of three basis functions, each window its own wave unit that
+    // contracts its three values against SIX column tiles (q|k|v of a head: 3 x O/32 = 6 tiles share x and the knots) --
+    // 288 accumulators, 18 MFMAs per basis evaluation, and a window evaluates only its own values (compile-time window start).
+    // Round 2's form (all 9 values x 2 tiles per wave, a 9-instruction select chain per value) spilled and lost to the LDS-tile kernel.
+    else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 && d->has_base &&
+             !((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16)) { p.nt = 6; p.njc = 3; }
+    else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
+    else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
+    else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }          // windows of 4 basis functions
+    else if (fam == KANVIT_FOURIER && p.gp == 56) { p.nt = 4; p.njc = 14; }
+    else return p;
+    if (d->I % 32 || d->O % 32 || d->M < 256) return p;
+    const int nshare = d->groups / d->x_group_mod;
+    p.shared = (kv_share_ok(fam, d->flags) && nshare > 1) ? 1 : 0;
+    p.nbg = p.shared ? d->x_group_mod : d->groups;
+    p.tiles_per_bg = (p.shared ? nshare : 1) * (d->O / 32);
+    p.nfb = d->I / 32;
+    if (fam == KANVIT_BSPLINE && p.tiles_per_bg <= 2) p.nt = 2;      // one unshared narrow layer: no point in four idle tiles per wave
+    p.nos = (p.tiles_per_bg + p.nt - 1) / p.nt;
+    // Small launches (the T / C geometries: 6400 rows, 2 heads): even at the shortest slab (64 tokens) the wave units cannot
+    // fill the chip, and a wave's MFMA chain (tokens x GP x NOT) IS the kernel time.  One column tile per wave instead of
+    // three: three times the waves, a third of the chain each; the basis is re-evaluated per wave (cheap against the chain).
+    if (fam == KANVIT_CHEBY && p.nt == 3 && (long long)p.nbg * p.nfb * p.nos * (d->M / 64) < 4LL * N_CU) {
+        p.nt = 1;
+        p.nos = p.tiles_per_bg;
+    }
+    // one live wave per SIMD (the accumulator block fills the register file): size the slab count so that the live waves
+    // (work-groups whose 2x2 wave grid is only partly populated retire their idle waves at once) cover the chip r times
+    const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
+    long long r = 1;
+    while (4LL * N_CU * r < units) ++r;
+    long long S = 4LL * N_CU * r / units;
+    const long long smax = d->M / 64;             // at least 64 tokens per slab (small M: parallelism beats slab traffic)
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    if (S > 65535) S = 65535;
+    const bool ln = fam == KANVIT_RBF && (d->flags & KANVIT_FLAG_FUSED_LN);
+    if (ln && S * 4096 < d->M) S = (d->M + 4095) / 4096;      // fused LayerNorm: a wave's (mean, rstd) strip is 8 bytes per slab row of LDS
+    if (S > 65535) return p;
+    long long rps = (d->M + S - 1) / S;
+    rps = (rps + 15) / 16 * 16;
+    if (ln && rps > 4096) return p;
+    p.rows_per_slab = rps;
+    p.slabs = (int)((d->M + rps - 1) / rps);
+    if (units > (1LL << 30)) return p;
+    {       // 32-bit in-slab element offsets (see the kernel)
+        long long ld = d->ldx > d->ldy ? d->ldx : d->ldy;
+        if (d->ldu > ld) ld = d->ldu;
+        if (rps * ld + ld >= (1LL << 29)) return p;
+    }
+    p.ws_bytes = p.slabs > 1 ? sizeof(float) * (size_t)p.slabs * d->groups * ((size_t)d->I * p.gp) * d->O : 0;
+    p.ok = true;
+    return p;
+}
+
+int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) { return dispatch_bwd_weight_reg(family, a, p, bf, st); }
+
+// dw[e] = sum over the `slabs` partial slabs (each `total` floats), in slab order
+int kv_slab_reduce(const float* slab, float* dw, long long total, int slabs, hipStream_t st) {
+    long long nb = (total + 255) / 256;
+    if (nb > 8 * N_CU) nb = 8 * N_CU;
+    hipLaunchKernelGGL(kan_slab_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, slab, dw, total, slabs);
+    KV_LAUNCH_CHECK("kan_slab_reduce_kernel");
+    return 0;
+}

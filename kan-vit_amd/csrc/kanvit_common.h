@@ -40,7 +40,6 @@ static inline int kv_fail(int code, const char* fmt, ...) {
 struct KvConfig {
     int no_reg;          // KANVIT_NO_REG          register-form KAN kernels off (LDS-tile kernels everywhere)
     int no_reg_bw;       // KANVIT_NO_REG_BW       register-form weight gradient off
-    int reg_bw_bspline;  // KANVIT_REG_BW_BSPLINE  register-form weight gradient for B-splines on (measured slower)
     int no_fast;         // KANVIT_NO_FAST         predicate-free variants of the LDS-tile kernels off
     int no_pipe;         // KANVIT_NO_PIPE         fp32 register kernels without the one-step-ahead LDS fragment prefetch (round-1 form)
     int no_ws;           // KANVIT_NO_WS           W-stationary bf16 forward off
