@@ -189,8 +189,10 @@ __device__ __forceinline__ bool kv_bspline_uniform(const float* __restrict__ kn,
     const float t = (xv - g0) * ih;
     const float fl = floorf(t);
     j0 = (int)fl;
-    if (!(t >= 0.0f) || j0 >= nk - 1) return false;
-    const float u = t - fl, u2 = u * u, u3 = u2 * u, om = 1.0f - u;
+    const bool in = (t >= 0.0f) && j0 < nk - 1;
+    // the values are ALWAYS formed, and finite (u = 0 outside the knot range, for NaN and for infinities): kv_bsel4 multiplies
+    // them by 0/1 masks, and a callers' `in ? ... : 0` select would cost the same instruction
+    const float u = in ? t - fl : 0.0f, u2 = u * u, u3 = u2 * u, om = 1.0f - u;
     const float s6 = 1.0f / 6.0f;
     bv[0] = om * om * om * s6;
     bv[1] = (3.0f * u3 - 6.0f * u2 + 4.0f) * s6;
@@ -202,16 +204,20 @@ __device__ __forceinline__ bool kv_bspline_uniform(const float* __restrict__ kn,
         dv[2] = (-1.5f * u2 + u + 0.5f) * ih;
         dv[3] = 0.5f * u2 * ih;
     }
-    return true;
+    return in;
 }
 
-// Value of basis jg for a point in knot interval j0 (the four non-zero values v[e] belong to bases j0-3+e).  Written as
-// compares of j0 against CONSTANTS (jg is one after unrolling): the compiler forms each lane mask (j0 == k) once and
-// shares it between the bases -- 11 v_cmp + 4 v_cndmask per basis instead of a 9-instruction select chain per basis.
-// Points outside the knot range carry j0 = KV_BSPLINE_OUT, which matches nothing (every basis 0, models/effkan.py:115).
+// Value of basis jg for a point in knot interval j0 (the four non-zero values v[e] belong to bases j0-3+e), branch-free:
+// lane masks (j0 == k) as 0/1 floats -- jg is a constant after unrolling, so each mask is formed once and shared between
+// the bases -- times the four values: 11 v_cndmask + 4 v_fma per basis, exact (one factor is 1, the others 0; the values
+// are finite).  A chain of `j0 == c ? v : ...` is what one would write; the compiler turns that into a switch over j0 with
+// divergent branches around every basis value.  Points outside the knot range carry j0 = KV_BSPLINE_OUT, which matches
+// nothing (every basis 0, models/effkan.py:115).
 constexpr int KV_BSPLINE_OUT = -64;
 __device__ __forceinline__ float kv_bsel4(int j0, int jg, const float (&v)[4]) {
-    return j0 == jg + 3 ? v[0] : (j0 == jg + 2 ? v[1] : (j0 == jg + 1 ? v[2] : (j0 == jg ? v[3] : 0.0f)));
+    const float m0 = (j0 == jg + 3) ? 1.0f : 0.0f, m1 = (j0 == jg + 2) ? 1.0f : 0.0f;
+    const float m2 = (j0 == jg + 1) ? 1.0f : 0.0f, m3 = (j0 == jg) ? 1.0f : 0.0f;
+    return __builtin_fmaf(m0, v[0], __builtin_fmaf(m1, v[1], __builtin_fmaf(m2, v[2], m3 * v[3])));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,7 +442,7 @@ struct BasisGenP {
             j0 = (int)fl;
             in = (tt >= 0.0f) && (j0 < nkm1);
             if (!in) j0 = KV_BSPLINE_OUT;
-            const float uu = tt - fl, u2 = uu * uu, u3 = u2 * uu, om = 1.0f - uu;
+            const float uu = in ? tt - fl : 0.0f, u2 = uu * uu, u3 = u2 * uu, om = 1.0f - uu;      // finite also for NaN / infinite x (kv_bsel4 multiplies by masks)
             const float s6 = 1.0f / 6.0f;
             bv[0] = om * om * om * s6;
             bv[1] = (3.0f * u3 - 6.0f * u2 + 4.0f) * s6;
@@ -456,11 +462,13 @@ struct BasisGenP {
             return p2;
         } else if constexpr (FAM == KV_BSPLINE) {
             const int jg = (J0C >= 0 ? J0C : j0w) + j;
-            if (jg >= G) return kv_silu(x);
+            if (J0C >= 0 && jg > 8) return 0.0f;                  // idle slot of the last window (9 = 5 + 4)
+            if (jg >= (J0C >= 0 ? 8 : G)) return kv_silu(x);      // compile-time windows: G = 8 (GP = 9 with the silu column; host-checked)
             return kv_bsel4(j0, jg, bv);
         } else if constexpr (FAM == KV_RBF) {
             const int jg = (J0C >= 0 ? J0C : j0w) + j;
-            if (jg >= G) return kv_silu(x);
+            if (J0C >= 0 && jg > 8) return 0.0f;
+            if (jg >= (J0C >= 0 ? 8 : G)) return kv_silu(x);
             return kv_sel8(pr, jg);            // compile-time jg: the unused Gaussians of a window are never computed (dead code)
         } else if constexpr (FAM == KV_FOURIER) {
             const float v = sin_half ? sk : ck;

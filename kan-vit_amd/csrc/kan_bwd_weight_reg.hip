@@ -21,17 +21,20 @@ namespace {
 template <int FAM, int GP, int NOT, bool BF, int JC = GP>
 __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
                                                                  int shared, int nbg) {
-    constexpr int NJC = GP / JC;                  // wide bases (G = 28) are contracted in NJC windows of JC basis functions,
+    constexpr int NJC = (GP + JC - 1) / JC;       // wide bases (G = 28) are contracted in NJC windows of JC basis functions,
                                                   // each its own wave unit (every window regenerates only its own values)
     constexpr bool RBF = (FAM == KV_RBF);
     constexpr int TS = BF ? 8 : 1;            // tokens per lane per step
-    constexpr bool BIG = !BF && JC * NOT >= 18 && NOT >= 6;   // 288 accumulators x six dY streams: room for three blocks of two steps, not two of four
-    constexpr int UB = BF ? 1 : (BIG ? 2 : 4);        // steps per prefetch block
-    constexpr int PD = (BF || BIG) ? 3 : 2;           // blocks in flight
+    constexpr int UB = BF ? 1 : 4;            // steps per prefetch block
+    constexpr int PD = BF ? 3 : 2;            // blocks in flight
     constexpr int NTOK = TS * UB;             // tokens per lane per block
-    // the wave index is uniform by construction; telling the compiler (readfirstlane) keeps everything derived from it -- unit
-    // and slab numbers, tile columns, the slab's base pointers -- in scalar registers instead of one vector register each
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hf = lane >> 5;
+    // The wave index is uniform by construction; telling the compiler (readfirstlane) keeps everything derived from it -- unit
+    // and slab numbers, tile columns, the slab's base pointers -- in scalar registers instead of one vector register each.
+    // Applied where the register file is the limit (B-spline / FastKAN, the G = 28 windows: it removes their scratch spills,
+    // FastKAN q|k|v 968 -> 945 us); the Chebyshev / linear / narrow-sine instantiations measured 7 % SLOWER with it (373 -> 401 us).
+    constexpr bool SCALAR_WAVE = FAM == KV_BSPLINE || FAM == KV_RBF || GP >= 28;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int wave = SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     // wave unit u = (basis group, column-tile set, feature block), feature block fastest: the 4 waves of a work-group are
     // always 4 live units (a partly populated work-group would leave SIMDs idle: one wave fills a SIMD's register file,
     // so the next work-group cannot start until ALL four SIMDs are free)
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
             tcol[i] = (long long)(shared ? ((os * NOT) / otpg) * a.xmod + bg : bg) * a.O + ((os * NOT) % otpg) * 32;
         }
     }
-    // B-spline / FastKAN windows (GP = 9 contracted as three windows of three basis functions, each its own wave unit): the
+    // B-spline / FastKAN windows (GP = 9 contracted as windows of JC basis slots, each its own wave unit): the
     // window start is made a COMPILE-TIME constant by a wave-uniform switch over three copies of the body -- the selection of
     // a window's values (kv_bsel4 lane masks, kv_sel8) then folds, and the Gaussians / spline pieces the window does not need
     // are never computed.  Every other instantiation runs the body once with the run-time window start j0.
@@ -216,15 +219,15 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int fr = fb * 32 + kv_acc_row(r, hf);
-                gb[((long long)fr * GP + j0 + j) * a.O] = acc[j][i][r];
+                if (GP % JC == 0 || j0 + j < GP) gb[((long long)fr * GP + j0 + j) * a.O] = acc[j][i][r];      // the last window of 9 = 5 + 4 carries one idle slot
             }
     }
     };
     if constexpr ((FAM == KV_BSPLINE || FAM == KV_RBF) && NJC > 1) {
         static_assert(NJC <= 3, "window switch covers three windows");
         if (jc == 0) run(std::integral_constant<int, 0>{});
-        else if (jc == 1) run(std::integral_constant<int, JC>{});
-        else run(std::integral_constant<int, 2 * JC>{});
+        else if (NJC == 2 || jc == 1) run(std::integral_constant<int, JC>{});
+        else if constexpr (NJC == 3) run(std::integral_constant<int, 2 * JC>{});
     } else {
         run(std::integral_constant<int, -1>{});
     }
@@ -277,7 +280,7 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
         case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
         case KANVIT_BSPLINE:      // exact fp32 only (the plan refuses bf16 mode: there the LDS-tile bf16 kernel runs)
-            return p.nt == 6 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 6, 3, false>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 3, false>(a, p, bf, st);
+            return p.nt == 3 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 3, 5, false>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 5, false>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:
             if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE, 28, 4, 4>(a, p, bf, st);
@@ -298,12 +301,13 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     const int fam = d->family;
     if (fam == KANVIT_LINEAR && p.gp == 1) p.nt = 6;
     else if (fam == KANVIT_CHEBY && p.gp == 5) p.nt = 3;
-    // BSPLINE (GP = 9: 8 cubic bases + silu): three windows of three basis functions, each window its own wave unit that
-    // contracts its three values against SIX column tiles (q|k|v of a head: 3 x O/32 = 6 tiles share x and the knots) --
-    // 288 accumulators, 18 MFMAs per basis evaluation, and a window evaluates only its own values (compile-time window start).
-    // Round 2's form (all 9 values x 2 tiles per wave, a 9-instruction select chain per value) spilled and lost to the LDS-tile kernel.
+    // BSPLINE (GP = 9: 8 cubic bases + silu): two windows of FIVE basis slots (0..4 | 5..7, silu, one idle slot), each window
+    // its own wave unit that contracts its values against three column tiles -- the Chebyshev schedule (240 accumulators, 15
+    // MFMAs per basis evaluation), a window evaluating only its own values (compile-time window start).  The idle slot
+    // costs 10 % of the MFMAs; 3 x 6 tiles (no idle slot, 288 accumulators) and round 2's 9 x 2 both spill accumulators
+    // inside the token loop (the allocator cannot place more than 256 of them) and lose to the LDS-tile kernel.
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 && d->has_base &&
-             !((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16)) { p.nt = 6; p.njc = 3; }
+             !((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16)) { p.nt = 3; p.njc = 2; }
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
     else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }          // windows of 4 basis functions
@@ -315,7 +319,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     p.nbg = p.shared ? d->x_group_mod : d->groups;
     p.tiles_per_bg = (p.shared ? nshare : 1) * (d->O / 32);
     p.nfb = d->I / 32;
-    if (fam == KANVIT_BSPLINE && p.tiles_per_bg <= 2) p.nt = 2;      // one unshared narrow layer: no point in four idle tiles per wave
+    if (fam == KANVIT_BSPLINE && p.tiles_per_bg <= 2) p.nt = 2;      // one unshared narrow layer: no idle column tile
     p.nos = (p.tiles_per_bg + p.nt - 1) / p.nt;
     // Small launches (the T / C geometries: 6400 rows, 2 heads): even at the shortest slab (64 tokens) the wave units cannot
     // fill the chip, and a wave's MFMA chain (tokens x GP x NOT) IS the kernel time.  One column tile per wave instead of

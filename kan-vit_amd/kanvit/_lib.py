@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkanvit.so")
+# KANVIT_LIB: another build of the library (A/B timing of kernel variants by the tools; reported by active_config())
+LIB_PATH = os.environ.get("KANVIT_LIB") or os.path.join(HERE, "libkanvit.so")
 
 LINEAR, CHEBY, BSPLINE, RBF, SINE, FOURIER = range(6)
 FLAG_BF16_MFMA = 1
@@ -136,7 +137,8 @@ def active_config() -> str:
     """The kernel-selection switches as read from KANVIT_* at load ("name=value ..."; all zero / empty = defaults): the
     library's (KvConfig) followed by the Python-side ones (py_switches)."""
     ps = py_switches()
-    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']}"
+    alt = f" lib={LIB_PATH}" if os.environ.get("KANVIT_LIB") else ""
+    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']}" + alt
 
 
 def reload_config() -> str:
