@@ -546,6 +546,9 @@ inline int kv_persistent_grid(int nbh, size_t lds_bytes) {
 }
 
 #ifdef KANVIT_CLOCK_PROBE
+#ifndef KV_CLK_TID
+#define KV_CLK_TID 0          // first lane of the stamped wave (-DKV_CLK_TID=256: wave 4, the younger partner of wave 0 on its SIMD)
+#endif
 // Diagnostic build only (never shipped: tools/README.md): one work-group in the middle of the grid stamps the shader clock
 // and the 100 MHz real-time counter around its lifetime and around the phases of its wave 0, so the clock the chip holds
 // DURING this kernel inside a real training step and the share of each phase can be read (MI355X_MICROARCH.md, "DVFS
@@ -553,7 +556,7 @@ inline int kv_persistent_grid(int nbh, size_t lds_bytes) {
 __device__ unsigned long long g_kv_clk[16];
 #define KV_CLK_BEGIN()                                                            \
     unsigned long long kv_t0 = 0, kv_r0 = 0, kv_tp = 0, kv_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  \
-    const bool kv_stamp = (blockIdx.x == gridDim.x / 2) && threadIdx.x == 0;      \
+    const bool kv_stamp = (blockIdx.x == gridDim.x / 2) && threadIdx.x == KV_CLK_TID;      \
     if (kv_stamp) { kv_t0 = kv_tp = __builtin_amdgcn_s_memtime(); kv_r0 = __builtin_amdgcn_s_memrealtime(); }
 #define KV_CLK_PHASE(i)                                                           \
     if (kv_stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long kv_now = __builtin_amdgcn_s_memtime(); kv_ph[i] += kv_now - kv_tp; kv_tp = kv_now; __builtin_amdgcn_sched_barrier(0); }
@@ -725,6 +728,248 @@ __global__ __launch_bounds__(KV_A3_THREADS, 2) void attn_fwd3_kernel(const AttnA
         }
         KV_CLK_PHASE(7)
     }   // heads
+    KV_CLK_END()
+}
+
+// =============================================================================================
+// forward, fourth form (exact fp32, D == 32*DT, N > 64, 16-byte aligned operands): the third form's mathematics with the
+// operand fills taken OFF the critical path.  In the third form a head's K and V (2 x 61 KB with padded rows) fill the LDS,
+// one work-group owns the CU, and nothing overlaps the fill of the next head: a fifth of the time is spent waiting for K / V
+// rows.  Here
+//   * the images are UNPADDED rows ([row][D] floats, 51 KB for 200 rows of 64) whose 16-byte slots are XOR-swizzled inside
+//     each 256-byte line (slot p of line l holds logical slot p ^ (l & 15)): the same conflict-free ds_read_b128 (lane = row)
+//     and ds_read_b32 (lane = column) as the padded image, in 84 % of the space -- THREE images fit the 160 KiB;
+//   * the fills are LDS-DMA (global_load_lds_dwordx4: no staging registers, one wave-instruction = 1 KiB of the image; the
+//     swizzle lives in the per-lane SOURCE address, cdna guide section 5 rule 21), issued one phase AHEAD into a ring of
+//     three buffers: item i of the sequence K0 V0 K1 V1 ... lives in buffer i % 3, its fill is issued at the start of phase
+//     i - 1 and lands while that phase's MFMAs run; each phase starts with s_waitcnt vmcnt(0) + ONE raw s_barrier (all
+//     pieces of item i have landed; every wave is done with phase i - 1, so buffer (i + 1) % 3 = (i - 2) % 3 is free);
+//   * the Q rows of the NEXT head are requested (plain loads into the dead Q registers) at the start of the P.V phase, so
+//     no plain load is ever consumed while a fill is in flight (hipcc would drain the whole queue there).
+// Rows >= N of an image repeat row N - 1 (finite values; their probabilities are exactly 0); the score tiles of the ragged
+// last key tile read up to 27 rows past the image (whatever the next buffer holds) and mask them by SELECT before any
+// arithmetic.  One work-group (8 waves: wave w owns query tile w) per CU, persistent over the (batch, head) pairs.
+// =============================================================================================
+typedef __attribute__((address_space(3))) void* kv_lds_ptr;
+typedef const __attribute__((address_space(1))) void* kv_glb_ptr;
+
+// rows [0, rows) of a [.][32*DT] fp32 matrix -> swizzled LDS image, by LDS-DMA; rows % (64 / (8*DT)) == 0
+template <int DT>
+__device__ __forceinline__ void kv_fill_glds(float* __restrict__ img, const float* __restrict__ src, long long stride_n, int rows, int N,
+                                             int first, int step, int lane) {
+    constexpr int SPR = 8 * DT;                   // 16-byte slots per row
+    const int npieces = rows * SPR / 64;
+    for (int p = first; p < npieces; p += step) {         // this wave's pieces: first, first + step, ... (wave-uniform)
+        const int phys = p * 64 + lane, line = phys >> 4;
+        const int logical = (phys & ~15) | ((phys & 15) ^ (line & 15));      // the swizzle is an involution
+        int row = logical / SPR;
+        const int sl = logical - row * SPR;
+        row = row < N ? row : N - 1;
+        __builtin_amdgcn_global_load_lds((kv_glb_ptr)(src + (long long)row * stride_n + 4 * sl), (kv_lds_ptr)(img + p * 256), 16, 0, 0);
+    }
+}
+
+constexpr int kv_a4_rows(int N) { return (N + 7) & ~7; }                   // image rows (whole 1-KiB pieces for D = 32 and 64)
+inline size_t kv_a4_lds(int N, int D) { return sizeof(float) * ((size_t)3 * kv_a4_rows(N) + 32) * D; }     // + the over-read of the last score tile
+
+template <int DT, int NKT>
+__global__ __launch_bounds__(KV_A3_THREADS, 2) void attn_fwd4_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, NW = KV_A3_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hf = lane >> 5;
+    const int N = a.N, nkt = a.nkt, nbh = a.B * a.H;
+    const int rows = kv_a4_rows(N), BUF = rows * D;                   // floats per image
+    const float sc2 = a.scale * LOG2E;
+    const int qt = wave;                                               // this wave's query tile
+    const bool has_tile = qt < nkt;
+    // Waves without a query tile (wave 7 at N = 197) are the LOADERS: they issue every LDS-DMA piece (~180 cycles of issue
+    // each, 13 per head and wave when all eight share them) and leave the computing waves' instruction streams alone.
+    const int nload = NW - nkt;
+    const bool loader = nload > 0 ? !has_tile : true;
+    const int lw = nload > 0 ? wave - nkt : wave, lstep = nload > 0 ? nload : NW;
+    const int qrow = qt * 32 + l31;
+    const bool qok = has_tile && qrow < N;
+    // per-lane LDS offsets (floats) of the fragment reads in the swizzled image:
+    //   K (lane = key row l31 of a tile, half hf takes d = 16*DT*hf + 4g + e): slot 4*DT*hf + g of line (row) -- row & 15 == l31 & 15
+    //   V (lane = column d = l31 + 32*dt of key row 8q + 4hf + e): slot (l31 >> 2) + 8*dt; (row & 15) = 8*(q & 1) + 4hf + e
+    static_assert(DT == 2, "the offsets below assume 256-byte rows (D = 64)");
+    int koff[4 * DT];
+#pragma unroll
+    for (int g = 0; g < 4 * DT; ++g) koff[g] = l31 * D + 4 * ((8 * hf + g) ^ (l31 & 15));
+    int voff[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) voff[e] = (4 * hf) * D + 4 * ((l31 >> 2) ^ (4 * hf + e)) + (l31 & 3);
+
+    float qf[16 * DT];
+    auto load_q = [&](int bh) {          // this lane's half row of Q (rows past N read row 0: their outputs are never stored)
+        const int bi = bh / a.H, hi = bh - bi * a.H;
+        const float* qp = a.q + bi * a.qsb + hi * a.qsh + (long long)(qok ? qrow : 0) * a.qsn + 16 * DT * hf;
+#pragma unroll
+        for (int s4 = 0; s4 < 4 * DT; ++s4) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(qp + 4 * s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[4 * s4 + e] = u0[e];
+        }
+    };
+    auto fill = [&](int item, const float* base, long long sn) {
+        if (loader) kv_fill_glds<DT>(smem + (item % 3) * BUF, base, sn, rows, N, lw, lstep, lane);
+    };
+    // the output tile of a head is stored AFTER the next phase's barrier, behind the next fill: issued at the end of its own
+    // phase, the stores would sit in front of the next phase's s_waitcnt vmcnt(0) and every wave would wait for them to drain
+    f32x16 oacc[DT];
+    float o_inv = 0.0f, o_lse = 0.0f;
+    float* o_ptr = nullptr;
+    float* lse_ptr = nullptr;
+    auto store_o = [&]() {
+        if (o_ptr) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {oacc[dt][4 * q] * o_inv, oacc[dt][4 * q + 1] * o_inv, oacc[dt][4 * q + 2] * o_inv, oacc[dt][4 * q + 3] * o_inv};
+                    *reinterpret_cast<f32x4*>(o_ptr + dt * 32 + 8 * q) = v;
+                }
+            if (lse_ptr) *lse_ptr = o_lse;
+            o_ptr = nullptr;
+        }
+    };
+
+    int item = 0;                                                      // K of head t is item 2t, V item 2t + 1
+    int bh = blockIdx.x;
+    KV_CLK_BEGIN()
+    if (bh < nbh) {
+        const int bi = bh / a.H, hi = bh - bi * a.H;
+        fill(0, a.k + bi * a.ksb + hi * a.ksh, a.ksn);
+        if (has_tile) load_q(bh);
+    }
+    for (; bh < nbh; bh += gridDim.x) {
+        const int bi = bh / a.H, hi = bh - bi * a.H;
+        // ---------------- phase S: scores and softmax from the K image (item), V fill in flight ----------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my pieces of K (and my Q rows) have arrived
+        // hipcc does not see that wait: it would wait for the Q registers itself at their first use -- AFTER the V fill below
+        // has been issued, i.e. for the whole fill (vmcnt retires in order).  An empty statement that "uses" them here makes its
+        // own wait land in front of the barrier, where nothing is in flight any more.
+#pragma unroll
+        for (int e = 0; e < 16 * DT; ++e) asm volatile("" : "+v"(qf[e]));
+        __builtin_amdgcn_s_barrier();                                  // ... and everybody's; the previous P.V phase is over
+        KV_CLK_PHASE(0)
+        fill(item + 1, a.v + bi * a.vsb + hi * a.vsh, a.vsn);
+        store_o();                                                     // the previous head's output tile
+        KV_CLK_PHASE(1)
+        const float* K_s = smem + (item % 3) * BUF;
+        f32x16 sacc[NKT];
+        float inv = 0.0f, lse_v = 0.0f;
+        if (has_tile) {
+            constexpr int NG = 4 * DT;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
+                if (j < nkt) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const f32x4 ka = *reinterpret_cast<const f32x4*>(K_s + j * 32 * D + koff[g]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[4 * g + e], sacc[j], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            KV_CLK_PHASE(2)
+            const int lim = a.causal ? (qrow + 1 < N ? qrow + 1 : N) : N;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if (j < nkt) {
+                    if ((j + 1) * 32 > N || a.causal) {      // wave-uniform: only the ragged last tile, or every tile when causal
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = j * 32 + kv_acc_row(r, hf);
+                            sacc[j][r] = (key >= lim) ? -INFINITY : sacc[j][r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mxs = (mx == -INFINITY) ? 0.0f : mx * sc2;
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if (j < nkt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[j][r] * sc2 - mxs);      // v_exp_f32: arguments <= 0, results in [0, 1]
+                        sacc[j][r] = p;
+                        sum += p;
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 32);
+            inv = 1.0f / sum;
+            lse_v = mx * a.scale + logf(sum);
+        }
+        ++item;
+        KV_CLK_PHASE(3)
+        // ---------------- phase P.V from the V image (item); the next head's K fill and Q rows in flight ----------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        KV_CLK_PHASE(4)
+        const int bhn = bh + gridDim.x;
+        if (bhn < nbh) {
+            const int bn = bhn / a.H, hn = bhn - bn * a.H;
+            fill(item + 1, a.k + bn * a.ksb + hn * a.ksh, a.ksn);
+            if (has_tile) load_q(bhn);
+        }
+        KV_CLK_PHASE(5)
+        if (has_tile) {
+            const float* V_s = smem + (item % 3) * BUF;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+            // O^T[d][query] = sum_key V[key][d] P[key][query], in quads of four k-steps (keys 8q + 4hf + e of key tile j).  The V
+            // values of quad i + 1 are read while the MFMAs of quad i issue (a read -> wait -> two MFMAs chain exposes the LDS
+            // latency on every pair: 154 cycles per MFMA measured instead of the 128 two waves of a SIMD can reach); the read
+            // ahead is unconditional -- past the last valid quad it reads rows that exist in the LDS and are never used.
+            const int nquads = (nkt - 1) * 4 + ((N - (nkt - 1) * 32 + 7) >> 3);      // quads that hold a valid key
+            float va[2][4][DT];
+            auto read_quad = [&](int qi, float (&dst)[4][DT]) {
+                const int jq = qi >> 2, qq = qi & 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)          // key row 32*jq + 8*qq + 4hf + e, column l31 + 32*dt: slot bit 3 = dt ^ (qq & 1)
+                        dst[e][dt] = V_s[voff[e] + (jq * 32 + 8 * qq + e) * D + 32 * (dt ^ (qq & 1))];
+            };
+            read_quad(0, va[0]);
+#pragma unroll
+            for (int qi = 0; qi < NKT * 4; ++qi) {
+                if (qi + 1 < NKT * 4) read_quad(qi + 1, va[(qi + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (qi < nquads) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+                            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[qi & 1][e][dt], sacc[qi >> 2][4 * (qi & 3) + e], oacc[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            KV_CLK_PHASE(6)
+            if (qok) {
+                o_ptr = a.out + bi * a.osb + hi * a.osh + (long long)qrow * a.osn + 4 * hf;
+                lse_ptr = (hf == 0 && a.lse) ? a.lse + (long long)bh * N + qrow : nullptr;
+                o_inv = inv;
+                o_lse = lse_v;
+            }
+        }
+        ++item;
+        KV_CLK_PHASE(7)
+    }
+    store_o();
     KV_CLK_END()
 }
 
@@ -1520,6 +1765,274 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv3_kernel(const AttnArgs a) 
     }   // heads
 }
 
+// =============================================================================================
+// backward, fourth form of the key-stationary kernel (exact fp32, D = 64, 64 < N <= 208): attn_bwd_kv3_kernel's mathematics
+// with NOTHING fetched at the head boundary.  The third form spends a fifth of a head there -- two synchronous 61 KB fills
+// (Q, dO), rowsum(dO*O) with one row per thread, the K / V rows of every wave -- and, the work-groups running in step, the
+// whole chip asks for its 250 KB per CU at the same moment (phase stamps: 35 k of 179 k cycles per head).  Here
+//   * Q and dO are unpadded XOR-swizzled 51 KB images (attn_fwd4_kernel's layout) filled by LDS-DMA into a ring of three
+//     buffers by the LOADER wave (wave 7: seven key tiles on eight waves), which also forms the (lse * log2 e, rowsum(dO*O))
+//     table of the next head from global memory;
+//   * head t computes from Q_t in buffer 2t % 3 and dO_t in buffer (2t + 1) % 3.  Q_{t+1} goes to the free third buffer.
+//     dO_{t+1} goes INTO THE Q_t BUFFER, query tile by query tile: the rows of tile qt are dead once every wave has finished
+//     its second products on them -- one barrier per query tile tells the loader so -- and by the end of the head only the
+//     ragged last tile's pieces are still in flight;
+//   * the K / V rows of the next head are requested into the (dead) fragment registers right after the LAST first products
+//     of a head, and land under its last second products.
+// The loader spreads its work over the query-tile intervals (a seventh of the Q image and of the table, then the barrier,
+// then eight dO pieces), so it never keeps the computing waves waiting.  The column-walking operands of the second products
+// (dO^T, Q^T) are read one half quad of k-steps ahead into a second register set.  dS goes to the workspace for
+// attn_bwd_dq3_kernel exactly as before (a dQ product inside this kernel would need the K tiles AND a cross-wave reduction
+// buffer in an LDS that is full).
+// =============================================================================================
+inline size_t kv_b4_lds(int N, int D) {
+    const int np = (N + 31) / 32 * 32, rows = kv_a4_rows(N);
+    return sizeof(float) * (((size_t)3 * rows + (np - rows)) * D + (size_t)2 * np * 2 + 8);      // images + over-read of the ragged tile + 2 x (lse, delta)[NP] + tile counters
+}
+
+// pieces [p0, p1) of a swizzled image (see kv_fill_glds), issued by ONE wave
+template <int DT>
+__device__ __forceinline__ void kv_fill_glds_range(float* __restrict__ img, const float* __restrict__ src, long long stride_n, int N, int p0,
+                                                   int p1, int lane) {
+    constexpr int SPR = 8 * DT;
+    for (int p = p0; p < p1; ++p) {
+        const int phys = p * 64 + lane, line = phys >> 4;
+        const int logical = (phys & ~15) | ((phys & 15) ^ (line & 15));
+        int row = logical / SPR;
+        const int sl = logical - row * SPR;
+        row = row < N ? row : N - 1;
+        __builtin_amdgcn_global_load_lds((kv_glb_ptr)(src + (long long)row * stride_n + 4 * sl), (kv_lds_ptr)(img + p * 256), 16, 0, 0);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_kv4_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(DT == 2, "256-byte rows (D = 64)");
+    constexpr int D = 32 * DT, NW = 8, NG = 4 * DT, PPT = 32 * D / 256;      // LDS-DMA pieces per 32-row tile (8)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hf = lane >> 5;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32, nbh = a.B * a.H;
+    const int rows = kv_a4_rows(N), BUF = rows * D, npieces = rows * D / 256;
+    float* ld_base = smem + 3 * BUF + (NP - rows) * D;                // [2][NP][2]: lse * log2(e) (+inf on pad rows), rowsum(dO*O)
+    // done[qt]: how many (wave, head) pairs have finished query tile qt -- monotonic, so nkt * (t + 1) once every computing
+    // wave is through tile qt of head t.  The loader polls it (it has nothing else to do); the computing waves never wait.
+    unsigned* done = reinterpret_cast<unsigned*>(ld_base + 2 * (2 * NP));
+    if (tid < 8) done[tid] = 0u;
+    const int jt = wave;                                              // this wave's key tile
+    const bool loader = jt >= nkt;                                    // host-checked: exactly the waves nkt .. 7; the FIRST of them loads
+    const float sc2 = a.scale * LOG2E;
+    const int nq_last = (N - (nkt - 1) * 32 + 7) >> 3;               // quads of k-steps of the last QUERY tile that hold a valid row
+    int koff[NG];                                                      // row-walking fragment reads (lane = row l31 of a tile), see attn_fwd4_kernel
+#pragma unroll
+    for (int g = 0; g < NG; ++g) koff[g] = l31 * D + 4 * ((8 * hf + g) ^ (l31 & 15));
+    int voff[4];                                                       // column-walking reads (lane = column l31 + 32*dt of row 8q + 4hf + e)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) voff[e] = (4 * hf) * D + 4 * ((l31 >> 2) ^ (4 * hf + e)) + (l31 & 3);
+
+    // (lse * log2 e, rowsum(dO * O)) of query rows [n_lo, n_hi) of head bhx -> ld[NP][2]; one wave, 4 lanes per row
+    auto table_rows = [&](int bhx, float* __restrict__ ld, int n_lo, int n_hi) {
+        const int bx = bhx / a.H, hx = bhx - bx * a.H;
+        const float* ob = a.o + bx * a.osb + hx * a.osh;
+        const float* dob = a.d_o + bx * a.osb + hx * a.osh;
+        const int sub = lane & 3, r0 = lane >> 2;
+        for (int n0 = n_lo; n0 < n_hi; n0 += 16) {
+            const int n = n0 + r0;
+            float dl = 0.0f;
+            if (n < N) {
+                const float* orow = ob + (long long)n * a.osn + 16 * sub;
+                const float* drow = dob + (long long)n * a.osn + 16 * sub;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 o4 = *reinterpret_cast<const f32x4*>(orow + 4 * c);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + 4 * c);
+                    dl += o4[0] * d4[0] + o4[1] * d4[1] + o4[2] * d4[2] + o4[3] * d4[3];
+                }
+            }
+            dl += __shfl_xor(dl, 1);
+            dl += __shfl_xor(dl, 2);
+            if (sub == 0 && n < n_hi) {
+                float2 v = {INFINITY, 0.0f};                          // pad rows: p = exp2(s - inf) = 0
+                if (n < N) v = {a.lse_in[(long long)bhx * N + n] * LOG2E, dl};
+                *reinterpret_cast<float2*>(ld + 2 * n) = v;
+            }
+        }
+    };
+    float kf[16 * DT], vf[16 * DT];
+    auto load_kv_rows = [&](int bhx) {                                // this lane's K and V rows (B-operand fragments) of head bhx
+        const int bx = bhx / a.H, hx = bhx - bx * a.H;
+        const int key = jt * 32 + l31;
+        const bool ok = key < N;
+        bf16x8_t unused0[1], unused1[1];
+        row_frags<DT, false>(a.k + bx * a.ksb + hx * a.ksh + (long long)(ok ? key : 0) * a.ksn, ok, hf, kf, unused0);
+        row_frags<DT, false>(a.v + bx * a.vsb + hx * a.vsh + (long long)(ok ? key : 0) * a.vsn, ok, hf, vf, unused1);
+    };
+
+    int t = 0;
+    int bh = blockIdx.x;
+    KV_CLK_BEGIN()
+    if (bh < nbh) {                                                    // prologue: the first head's images (all waves), table, K / V rows
+        const int bi = bh / a.H, hi = bh - bi * a.H;
+        kv_fill_glds<DT>(smem, a.q + bi * a.qsb + hi * a.qsh, a.qsn, rows, N, wave, NW, lane);
+        kv_fill_glds<DT>(smem + BUF, a.d_o + bi * a.osb + hi * a.osh, a.osn, rows, N, wave, NW, lane);
+        if (jt == nkt) table_rows(bh, ld_base, 0, NP);
+        if (!loader) load_kv_rows(bh);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 16 * DT; ++e) {
+            asm volatile("" : "+v"(kf[e]));
+            asm volatile("" : "+v"(vf[e]));
+        }
+    }
+    for (; bh < nbh; bh += gridDim.x, ++t) {
+        const int bi = bh / a.H, hi = bh - bi * a.H;
+        const int qb_i = (2 * t) % 3;                                  // buffer of Q_t; dO_t sits in (2t + 1) % 3, (2t + 2) % 3 is free
+        float* Q_s = smem + qb_i * BUF;
+        float* dO_s = smem + ((2 * t + 1) % 3) * BUF;
+        const float* ld_s = ld_base + (t & 1) * (2 * NP);
+        const int bhn = bh + gridDim.x;
+        const bool more = bhn < nbh;
+        // ---- head boundary: what the loader fetched during head t - 1 has arrived (the loader waits for its own LDS-DMA; the
+        //      computing waves waited for their K / V rows before their last stores, below, and leave those stores draining)
+        if (loader) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        KV_CLK_PHASE(0)
+        if (loader) {
+            // one seventh of the next head's Q image and table per query-tile interval, then -- once the computing waves have
+            // all left this tile's Q rows -- the dO rows of the next head into them
+            const int bn = more ? bhn / a.H : 0, hn = more ? bhn - bn * a.H : 0;
+            float* Qn = smem + ((2 * t + 2) % 3) * BUF;
+            float* ldn = ld_base + ((t + 1) & 1) * (2 * NP);
+            const int qchunk = (npieces + nkt - 1) / nkt;
+            for (int qt = 0; qt < nkt; ++qt) {
+                if (more && jt == nkt) {
+                    const int p0 = qt * qchunk, p1 = (p0 + qchunk < npieces) ? p0 + qchunk : npieces;
+                    kv_fill_glds_range<DT>(Qn, a.q + bn * a.qsb + hn * a.qsh, a.qsn, N, p0, p1, lane);
+                    table_rows(bhn, ldn, qt * 32, qt * 32 + 32);
+                }
+                if (more && jt == nkt) {                               // every computing wave is done with the Q rows of tile qt?
+                    const unsigned want = (unsigned)nkt * (unsigned)(t + 1);
+                    while (*reinterpret_cast<volatile unsigned*>(done + qt) < want) __builtin_amdgcn_s_sleep(16);
+                }
+                if (more && jt == nkt) {
+                    const int p0 = qt * PPT, p1 = (p0 + PPT < npieces) ? p0 + PPT : npieces;
+                    kv_fill_glds_range<DT>(Q_s, a.d_o + bn * a.osb + hn * a.osh, a.osn, N, p0, p1, lane);
+                }
+            }
+            continue;                                                  // wave-uniform: a loader has no key tile
+        }
+
+        const int key = jt * 32 + l31;
+        const bool key_ok = key < N;
+        f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[dt][r] = 0.0f;
+                dvacc[dt][r] = 0.0f;
+            }
+        // dS[q][key] rows of this head and key tile: a wave-UNIFORM base (scalar registers) + one per-lane offset; written
+        // as 16 per-lane 64-bit row pointers the compiler keeps 32 vector registers for them and spills inside the tile loop
+        float* dsb = a.ds + ((long long)bh * NP) * NP + jt * 32;
+        const int ds_lane = 4 * hf * NP + l31;
+        for (int qt = 0; qt < nkt; ++qt) {
+            const float* qrp = Q_s + qt * 32 * D;
+            const float* drp = dO_s + qt * 32 * D;
+            // ---- S[q][key] = Q.K^T and dP[q][key] = dO.V^T, two independent accumulation chains interleaved
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(qrp + koff[g]);
+                const f32x4 da = *reinterpret_cast<const f32x4*>(drp + koff[g]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[4 * g + e], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], vf[4 * g + e], pacc, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (qt == nkt - 1 && more) load_kv_rows(bhn);             // the fragment registers are dead: the next head's rows land under the rest of this tile
+            KV_CLK_PHASE(2)
+            const int nq = (qt == nkt - 1) ? nq_last : 4;
+            // second products' operands: dO^T / Q^T columns of query rows qt*32 + 8q + 2p + {0, 1} + 4hf -- half quads (two
+            // k-steps) read one half quad ahead into a second register set (a full quad ahead spills)
+            float da2[2][2][DT], qa2[2][2][DT];
+            auto read_half = [&](int hq, int b) {          // hq = 2*q + p
+                const int q = hq >> 1, e0 = 2 * (hq & 1);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const int off = voff[e0 + e] + (8 * q + e0 + e) * D + 32 * (dt ^ (q & 1));
+                        da2[b][e][dt] = drp[off];
+                        qa2[b][e][dt] = qrp[off];
+                    }
+            };
+            read_half(0, 0);
+            // ---- p = exp(s*scale - lse), ds = p * scale * (dp - delta)        (utils.py:278-287)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = qt * 32 + kv_acc_row(r, hf);
+                const float2 ld = *reinterpret_cast<const float2*>(ld_s + 2 * qrow);
+                float p = __builtin_amdgcn_exp2f(sacc[r] * sc2 - ld.x);      // v_exp_f32: exp2(-inf) = 0 on pad rows
+                if (!key_ok || (a.causal && key > qrow) || qrow >= N) p = 0.0f;      // (rows past the image hold another buffer's bits)
+                sacc[r] = p;
+                pacc[r] = p == 0.0f ? 0.0f : p * a.scale * (pacc[r] - ld.y);
+            }
+            KV_CLK_PHASE(3)
+            {       // dS[q][key] for the dQ kernel: row = q (register), 32 consecutive keys per lane half
+                float* dsp = dsb + (long long)(qt * 32) * NP;                                     // uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) (dsp + ((r & 3) + 8 * (r >> 2)) * NP)[ds_lane] = pacc[r];      // row kv_acc_row(r, hf)
+            }
+            KV_CLK_PHASE(4)
+            // ---- dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]: k-step r <-> query row
+            //      qt*32 + kv_acc_row(r, hf); the ragged last query tile contributes only its valid rows (p = ds = 0 elsewhere)
+#pragma unroll
+            for (int hq = 0; hq < 8; ++hq) {
+                if (hq + 1 < 8) read_half(hq + 1, (hq + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((hq >> 1) < nq) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(da2[hq & 1][e][dt], sacc[2 * hq + e], dvacc[dt], 0, 0, 0);
+                            dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa2[hq & 1][e][dt], pacc[2 * hq + e], dkacc[dt], 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            KV_CLK_PHASE(5)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my LDS reads of this tile's Q rows have returned:
+            if (lane == 0) __hip_atomic_fetch_add(done + qt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // tell the loader
+            KV_CLK_PHASE(6)
+        }
+        if (more) {
+            // the next head's K / V rows (requested under the last first products): an empty statement "using" the registers
+            // makes hipcc place ITS wait for those loads here, in front of the dK / dV stores -- a counted wait that leaves the
+            // dS stores draining; the head boundary then waits for nothing
+#pragma unroll
+            for (int e = 0; e < 16 * DT; ++e) {
+                asm volatile("" : "+v"(kf[e]));
+                asm volatile("" : "+v"(vf[e]));
+            }
+        }
+        if (key_ok) {
+            store_acc_rows<DT>(a.dk + bi * a.ksb + hi * a.ksh + (long long)key * a.ksn, dkacc, hf, 1.0f);
+            store_acc_rows<DT>(a.dv + bi * a.vsb + hi * a.vsh + (long long)key * a.vsn, dvacc, hf, 1.0f);
+        }
+        KV_CLK_PHASE(7)
+    }
+    KV_CLK_END()
+}
+
 // dQ from the stored dS: dQ^T[d][q] = sum_key K^T[d][key] dS[q][key].  K in LDS (A operand, lanes walk d: one ds_read2_b32
 // for the two d tiles of a key); the B operand is 16 consecutive keys of the lane's own dS row per key tile (lane half h
 // takes keys 16h + s: float4 loads one key tile ahead).  Fragments are read one quad of k-steps ahead; the ragged last
@@ -1653,8 +2166,28 @@ int launch_fwd3(const AttnArgs& a, hipStream_t st) {
     return 0;
 }
 
+template <int NKT>
+int launch_fwd4(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = kv_a4_lds(a.N, 64);
+    KV_ALLOW_LDS(160 * 1024, (attn_fwd4_kernel<2, NKT>));
+    const int nbh = a.B * a.H;
+    const int g = kv_config().attn_grid > 0 ? kv_config().attn_grid : KV_N_CU;       // one work-group per CU (three images fill its LDS)
+    hipLaunchKernelGGL((attn_fwd4_kernel<2, NKT>), dim3((unsigned)(nbh < g ? nbh : g)), dim3(KV_A3_THREADS), lds, st, a);
+    KV_LAUNCH_CHECK("attn_fwd4_kernel");
+    return 0;
+}
+
 template <int DT, bool BF>
 int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
+    if constexpr (!BF && DT == 2) {
+        // fourth form: D = 64, 64 < N (below, a head is a few tiles and the third form's single fill is cheap), three swizzled
+        // images within the 160 KiB, 16-byte aligned rows for the LDS-DMA fills
+        if (a.vec && a.D == 64 && a.nkt >= 3 && a.nkt <= 7 && kv_a4_lds(a.N, 64) <= 160 * 1024 && !kv_config().attn_v1 && !kv_config().attn_v2 &&
+            !kv_config().attn_v3 && (((uintptr_t)a.out | (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 == 0)) {
+            if (a.nkt <= 4) return launch_fwd4<4>(a, st);
+            return launch_fwd4<7>(a, st);
+        }
+    }
     if constexpr (!BF) {
         if (a.vec && a.D == 32 * DT && ((uintptr_t)a.out % 16 == 0) && !kv_config().attn_v1 && !kv_config().attn_v2) {
             if (a.nkt <= 1) return launch_fwd3<DT, 1>(a, st);
@@ -1687,6 +2220,30 @@ int launch_bwd2(const AttnArgs& a, hipStream_t st) {
     KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv2_kernel<DT, BF, false>));
     KV_ALLOW_LDS(160 * 1024, (attn_bwd_q2_kernel<DT, BF>));
     if constexpr (!BF) {
+        if constexpr (DT == 2) {
+            // fourth form of the key-stationary kernel (LDS-DMA ring, loader wave): D = 64, 64 < N, a wave without a key tile
+            if (a.ds && a.third && a.nkt >= 3 && a.nkt <= 7 && kv_b4_lds(a.N, D) <= 160 * 1024 && !kv_config().attn_v3 &&
+                (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.o | (uintptr_t)a.d_o) % 16 == 0)) {
+                const size_t lds4 = kv_b4_lds(a.N, D), ldsq = sizeof(float) * (size_t)NP * kv_pad4(D);
+                const int nbh = a.B * a.H;
+                const int g4 = kv_config().attn_grid > 0 ? kv_config().attn_grid : KV_N_CU;
+                if (a.nkt <= 4) {
+                    KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv4_kernel<2>));
+                    KV_ALLOW_LDS(160 * 1024, (attn_bwd_dq3_kernel<DT, 4>));
+                    hipLaunchKernelGGL((attn_bwd_kv4_kernel<2>), dim3((unsigned)(nbh < g4 ? nbh : g4)), dim3(512), lds4, st, a);
+                    KV_LAUNCH_CHECK("attn_bwd_kv4_kernel");
+                    hipLaunchKernelGGL((attn_bwd_dq3_kernel<DT, 4>), dim3((unsigned)kv_persistent_grid(nbh, ldsq)), dim3(512), ldsq, st, a);
+                } else {
+                    KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv4_kernel<2>));
+                    KV_ALLOW_LDS(160 * 1024, (attn_bwd_dq3_kernel<DT, 8>));
+                    hipLaunchKernelGGL((attn_bwd_kv4_kernel<2>), dim3((unsigned)(nbh < g4 ? nbh : g4)), dim3(512), lds4, st, a);
+                    KV_LAUNCH_CHECK("attn_bwd_kv4_kernel");
+                    hipLaunchKernelGGL((attn_bwd_dq3_kernel<DT, 8>), dim3((unsigned)kv_persistent_grid(nbh, ldsq)), dim3(512), ldsq, st, a);
+                }
+                KV_LAUNCH_CHECK("attn_bwd_dq3_kernel");
+                return 0;
+            }
+        }
         if (a.ds && a.third) {      // third form: same dS hand-off, pipelined LDS reads, rowsum(dO*O) in the prologue
             const size_t lds3 = sizeof(float) * ((size_t)2 * NP * kv_pad4(D) + 2 * (size_t)NP);
             const size_t ldsq = sizeof(float) * (size_t)NP * kv_pad4(D);
@@ -1913,7 +2470,7 @@ bool attn_small_ok(const kanvit_attn_desc* d) { return d->N <= 32 && d->D <= 32 
 extern "C" {
 
 #ifdef KANVIT_CLOCK_PROBE
-int kanvit_debug_clock(unsigned long long* out) {      // diagnostic build only: {shader cycles, 100 MHz ticks} of the stamped work-group
+__attribute__((visibility("default"))) int kanvit_debug_clock(unsigned long long* out) {      // diagnostic build only: {shader cycles, 100 MHz ticks} of the stamped work-group
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kv_clk), 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
 }
 #endif

@@ -127,14 +127,15 @@ static void kv_config_load() {
     c.no_tiny = flag("KANVIT_NO_TINY");
     c.attn_v1 = flag("KANVIT_ATTN_V1");
     c.attn_v2 = flag("KANVIT_ATTN_V2");
+    c.attn_v3 = flag("KANVIT_ATTN_V3");
     c.attn_no_ds = flag("KANVIT_ATTN_NO_DS");
     c.attn_grid = num("KANVIT_ATTN_GRID");
     c.ff_grid = num("KANVIT_FF_GRID");
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
-             c.no_reg, c.no_reg_bw, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
+             "no_reg=%d no_reg_bw=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
+             c.no_reg, c.no_reg_bw, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }

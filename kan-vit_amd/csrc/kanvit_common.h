@@ -48,6 +48,7 @@ struct KvConfig {
     int no_fused_ln;     // KANVIT_NO_FUSED_LN     kanvit_layer_ln_fusable() answers 0: FastKAN's LayerNorm stays a separate op
     int attn_v1;         // KANVIT_ATTN_V1         first-form attention kernels
     int attn_v2;         // KANVIT_ATTN_V2         second-form fp32 attention kernels (round 1) instead of the pipelined third form
+    int attn_v3;         // KANVIT_ATTN_V3         third-form fp32 attention kernels (round 2) instead of the LDS-DMA ring of the fourth form
     int attn_no_ds;      // KANVIT_ATTN_NO_DS      fp32 attention backward without the dS hand-off
     int ff_grid;         // KANVIT_FF_GRID         work-groups of the fused small feed-forward backward (tuning; 0 = default)
     int attn_grid;       // KANVIT_ATTN_GRID       work-groups of the persistent attention kernels (tuning; 0 = one round of resident ones)

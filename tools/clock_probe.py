@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, '..', 'kan-vit_amd'))
 import torch
 from kanvit import _lib
-_lib.LIB_PATH = os.path.join(HERE, '_diag', 'libkanvit_clk.so')
+_lib.LIB_PATH = os.environ.get('KANVIT_LIB') or os.path.join(HERE, '_diag', 'libkanvit_clk.so')
+fwd_only = 'fwd' in sys.argv[1:]        # stamps of the forward kernel (the backward kernels overwrite them otherwise)
 from kanvit import ops
 from attention import MSA
 torch.manual_seed(0)
@@ -18,11 +19,13 @@ h.kanvit_debug_clock.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 out = (ctypes.c_ulonglong * 10)()
 for it in range(12):
     y = m(x)
-    y.square().sum().backward()
+    if not fwd_only:
+        y.square().sum().backward()
     if it >= 8:
         torch.cuda.synchronize()
         h.kanvit_debug_clock(out)
         cyc, ticks = out[0], out[1]
         print(f"iter {it}: stamped work-group lived {cyc} shader cycles = {ticks / 100:.1f} us -> in-kernel clock {cyc / (ticks * 10):.3f} GHz")
-        names = ["wait+LDS fill", "issue prefetch", "Q load", "S phase", "softmax", "PV phase", "store", "tile-loop exit/wait"]
+        names = (["wait+barrier (S)", "issue V fill", "S MFMAs", "softmax", "wait+barrier (PV)", "issue K fill + Q loads", "PV MFMAs", "store"] if fwd_only else
+                 ["head boundary (wait + barrier)", "-", "S and dP MFMAs", "exp / dS", "dS stores", "dV and dK MFMAs", "tile barrier", "dK / dV store"])
         print("    wave 0 phases (cycles): " + ", ".join(f"{n} {out[2 + i]}" for i, n in enumerate(names)))
