@@ -101,15 +101,35 @@ __device__ __forceinline__ void kv_sincos(float x, float& s, float& c) {
     s = (q & 2) ? -ss : ss;
     c = ((q + 1) & 2) ? -cc : cc;
 }
+// One value only (SineKAN evaluates one sine -- or, in the input gradient, one cosine -- per (row, feature, grid point), and
+// these layers are bound by exactly this VALU work): reduce by PI instead of PI/2, k = rint(x/pi), r = x - k*pi in
+// [-pi/2, pi/2] (three-term Cody-Waite, exact products through fma), sin(x) = (-1)^k sin(r) with ONE odd polynomial
+// r + r^3 (S1 + S2 r^2 + S3 r^4 + S4 r^6) (weighted minimax fit, approximation error 4.7e-9; 1.2e-7 absolute evaluated in
+// fp32 for |x| up to 256, against 9e-8 for kv_sincos) and the sign as an XOR on the sign bit: 14 VALU instructions where
+// kv_sincos needs 24 for a value whose quadrant swap drags both polynomials along.  cos(x) = sin(x + pi/2) is the same with
+// the half-integer multiplier k - 1/2, k = rint(x/pi + 1/2): (k - 1/2) * PI_A is still an exact fp32 product.
+__device__ __forceinline__ float kv_sin_poly(float r, float k) {
+    const float r2 = r * r;
+    float p = fmaf(r2, 2.6001134756370448e-06f, -0.00019806642376352102f);
+    p = fmaf(p, r2, 0.00833301804959774f);
+    p = fmaf(p, r2, -0.16666656732559204f);
+    const float s = fmaf(p * r2, r, r);
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) ^ ((unsigned)(int)k << 31));      // odd k: negate
+}
 __device__ __forceinline__ float kv_sin(float x) {
-    float s, c;
-    kv_sincos(x, s, c);
-    return s;
+    const float k = rintf(x * 0.3183098861837907f);
+    float r = fmaf(k, -3.140625f, x);
+    r = fmaf(k, -9.67502593994140625e-4f, r);
+    r = fmaf(k, -1.509957990978376432e-7f, r);
+    return kv_sin_poly(r, k);
 }
 __device__ __forceinline__ float kv_cos(float x) {
-    float s, c;
-    kv_sincos(x, s, c);
-    return c;
+    const float k = rintf(fmaf(x, 0.3183098861837907f, 0.5f));
+    const float kk = k - 0.5f;
+    float r = fmaf(kk, -3.140625f, x);
+    r = fmaf(kk, -9.67502593994140625e-4f, r);
+    r = fmaf(kk, -1.509957990978376432e-7f, r);
+    return kv_sin_poly(r, k);
 }
 
 __device__ __forceinline__ float kv_silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -310,7 +310,9 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
              !((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16)) { p.nt = 3; p.njc = 2; }
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
-    else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }          // windows of 4 basis functions
+    // SINE G = 28: windows of 4 basis functions x 4 column tiles.  (Windows of 2 x 6 tiles -- 12 MFMAs per pair of sines instead
+    // of 16 per four, 7.4 -> 4.4 VALU instructions per MFMA -- measured SLOWER, 8.6 -> 13.1 ms: twice the wave units re-read dY.)
+    else if (fam == KANVIT_SINE && p.gp == 28) { p.nt = 4; p.njc = 7; }
     else if (fam == KANVIT_FOURIER && p.gp == 56) { p.nt = 4; p.njc = 14; }
     else return p;
     if (d->I % 32 || d->O % 32 || d->M < 256) return p;

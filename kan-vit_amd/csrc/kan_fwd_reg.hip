@@ -284,6 +284,9 @@ int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
     if (kv_config().no_reg) return 1;
     if (FAM == KV_BSPLINE && !((a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3)) return 1;
     if (FAM == KV_RBF && !kv_rbf_reg_ok(a.flags, a.G)) return 1;
+    // (Measured and rejected, round 3: EIGHT column tiles per generated value for SineKAN's G = 28 patch embedding -- it halves the
+    // sine evaluations per MFMA, 5.5 -> 2.9 VALU instructions, but its 114 KB of W per work-group leave one wave per SIMD:
+    // 10.06 -> 10.49 ms.)
     const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     if (a.O % (32 * nt)) return 1;
     const int nshare = a.groups / a.xmod;
