@@ -71,11 +71,8 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
     auto load_w = [&](int ci, int g, int cn) {
         const float* src = a.w + ((long long)g * a.K + (long long)ci * IC * GP) * a.O + cn * 32;
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (kofs[q] >= 0) t = *reinterpret_cast<const f32x4*>(src + kofs[q] + nofs[q]);
-            wreg[q] = t;
-        }
+        for (int q = 0; q < WQ; ++q)      // unconditional (a predicated load is a branch around it and a full vmcnt(0) wait at its use):
+            wreg[q] = *reinterpret_cast<const f32x4*>(src + (kofs[q] >= 0 ? kofs[q] : 0) + nofs[q]);      // padding rows re-read row 0, zeroed in store_w
     };
     auto store_w = [&](int buf) {
         float* dst = W_s + buf * WSZ;
@@ -87,7 +84,7 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int n = nofs[q] + e;                    // n within the 32-column chunk: n = h*16 + s
-                    dst[(n & 15) * WS2 + (n >> 4) * HOFF + kr] = wreg[q][e];
+                    dst[(n & 15) * WS2 + (n >> 4) * HOFF + kr] = kofs[q] >= 0 ? wreg[q][e] : 0.0f;
                 }
             }
         }

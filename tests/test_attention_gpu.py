@@ -165,3 +165,45 @@ def test_cross_attention_shapes_are_refused_not_misread():
         ops.attention(q, torch.randn(2, 2, 40, 16, device=DEV), torch.randn(2, 2, 40, 16, device=DEV))
     with pytest.raises(NotImplementedError):                            # key-padding masks: out of scope, loud
         FlashAttentionFunction.apply(q, q, q, torch.ones(2, 40, dtype=torch.bool, device=DEV), False, 512, 512)
+
+
+@pytest.mark.parametrize("n", [65, 96, 127, 128, 129, 160, 197, 200, 201, 208])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fourth_form_ring_kernels(n, causal, monkeypatch):
+    """The LDS-DMA ring kernels (attn_fwd4 / attn_bwd_kv4: D = 64, 64 < N <= 208) at every tile-count / ragged-tile case, with
+    MORE heads than work-groups (KANVIT_ATTN_GRID = 5: each persistent work-group walks 6 heads, i.e. the three-buffer ring, the
+    loader wave's progressive dO fill and the tile counters wrap around twice) -- against the fp64 oracle, and against the
+    third-form kernels (KANVIT_ATTN_V3) on the same inputs."""
+    from kanvit import _lib, ops
+    torch.manual_seed(1000 + n)
+    b, h, d = 5, 6, 64
+    q, k, v = (torch.randn(b, h, n, d) * 1.2 for _ in range(3))
+    do = torch.randn(b, h, n, d)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = ko.attention_reference(qd, kd, vd, causal=causal)
+    o_ref.backward(do.double())
+
+    def run():
+        qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        o = ops.attention(qg, kg, vg, causal=causal)
+        o.backward(do.to(DEV))
+        return o.detach().cpu(), qg.grad.cpu(), kg.grad.cpu(), vg.grad.cpu()
+
+    monkeypatch.setenv("KANVIT_ATTN_GRID", "5")
+    assert "attn_grid=5" in _lib.reload_config()
+    try:
+        ring = run()
+        again = run()
+        monkeypatch.setenv("KANVIT_ATTN_V3", "1")
+        assert "attn_v3=1" in _lib.reload_config()
+        third = run()
+    finally:
+        monkeypatch.delenv("KANVIT_ATTN_GRID")
+        monkeypatch.delenv("KANVIT_ATTN_V3", raising=False)
+        _lib.reload_config()
+    assert all(torch.equal(a, c) for a, c in zip(ring, again))            # no atomics, fixed order: bitwise run to run
+    assert max_err(ring[0], o_ref) < 1e-5
+    for g, ref in zip(ring[1:], (qd.grad, kd.grad, vd.grad)):
+        assert close(g, ref)
+    for a, c in zip(ring, third):                                        # same mathematics, same summation order per tile
+        assert max_err(a, c) < 2e-6 * max(1.0, float(c.abs().max()))

@@ -1,5 +1,5 @@
 """Run one kanvit op in a loop (for rocprofv3 --pmc passes on a single kernel).
-  python tools/bench_op.py fwd|bwd [amp] [iters]                 one MSA block (ViT-B geometry, ChebyKAN)
+  python tools/bench_op.py fwd|bwd [amp] [iters] [type] [vits]   one MSA block (ViT-B geometry, ChebyKAN; or another type / ViT-S)
   python tools/bench_op.py layer <type> [amp] [iters]            the fused patch embedding of a ViT-B model of <type>, forward + backward"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'kan-vit_amd'))
@@ -22,8 +22,10 @@ if what == 'layer':
         out.float().square().sum().backward()
 else:
     from attention import MSA
-    m = MSA(768, 12, type='cheby').cuda()
-    x = torch.randn(128, 197, 768, device='cuda', requires_grad=True)
+    t = next((a for a in sys.argv[2:] if a in ('cheby', 'vanilla', 'fast', 'efficientkan', 'sine')), 'cheby')
+    d, h, b = (384, 6, 256) if 'vits' in sys.argv[2:] else (768, 12, 128)
+    m = MSA(d, h, type=t).cuda()
+    x = torch.randn(b, 197, d, device='cuda', requires_grad=True)
     for _ in range(iters):
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
             y = m(x)
