@@ -53,7 +53,9 @@ extern "C" {
                                     RBF with G = 8: the centres are c0 + j/rbf_inv_h (FastKAN's own grid, models/
                                     fastkan.py:22-27: linspace centres, denominator = their spacing) -> the eight
                                     Gaussians come from two exp anchors and a two-step recurrence instead of eight
-                                    exps (relative error <= ~2e-6); the caller vouches for the layout.             */
+                                    exps (relative error <= ~2e-6 where the anchor exp(-(t-2)^2) / exp(-(t-5)^2) is a
+                                    normal number; beyond, values below 4e-24 are flushed to 0: absolute error
+                                    <= 4e-24); the caller vouches for the layout.                                  */
 #define KANVIT_FLAG_FUSED_LN 8   /* RBF (FastKAN): the LayerNorm in front of the spline path (models/fastkan.py:68) is formed IN the
                                     kernels: u = (x - mean) * rstd * gamma + beta over the I features of the group's x slice,
                                     eps = ln_eps.  bparams of a group = [centres(G) | gamma(I) | beta(I)].  The `u` argument

@@ -45,9 +45,11 @@ __device__ __forceinline__ float kv_tanh(float x) {
 // t = (u - c0)/h the basis is exp(-(t - j)^2) and phi_{j+1} = phi_j * exp(2t - 1) * exp(-2j).  Two anchors (j = 2 and 5) by
 // exp, every other value at most two steps away: 3 v_exp + 1 v_rcp + 12 v_mul for the eight values instead of eight times
 // (sub, mul, mul, mul, exp) -- the RBF kernels are bound by this VALU work, not by the matrix pipe.
-// Error: two steps x ~2 ulp (the ratio exp(2t - 1) is formed with a compensated argument, kv_exp_comp) ~ 5e-7 relative.  An anchor that
-// underflows (|t - 2| or |t - 5| > 9.3) zeroes values whose true size is < 3e-30; t is clamped so exp(2t - 1) stays finite
-// (everything is 0 out there); the compare form of the clamp lets a NaN input stay a NaN.
+// Error: two steps x ~2 ulp (the ratio exp(2t - 1) is formed with a compensated argument, kv_exp_comp) ~ 5e-7 RELATIVE wherever the
+// anchor is a normal number.  v_exp_f32 has no denormal range, so an anchor that underflows (|t - 2| or |t - 5| > ~9.35) takes its
+// neighbours to exactly 0 with it: the largest value lost that way is p[0] = exp(-t^2) just past t = -7.35, 3.5e-24 (ABSOLUTE error
+// <= 4e-24; the relative error is 100 % in that tail, which no training step can see).  t is clamped so exp(2t - 1) stays
+// finite (everything is 0 out there); the compare form of the clamp lets a NaN input stay a NaN.
 // exp(x) with the rounding of x*log2(e) compensated (the fast __expf loses |x| * 6e-8 relative there: 8e-7 at x = 13, and the
 // recurrence below multiplies by this value up to twice); v_exp_f32's own ~1 ulp remains
 __device__ __forceinline__ float kv_exp_comp(float x) {
