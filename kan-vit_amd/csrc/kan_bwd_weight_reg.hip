@@ -233,6 +233,155 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     }
 }
 
+// =============================================================================================
+// The same streaming weight gradient on 16-ROW tiles (exact fp32, v_mfma_f32_16x16x4_f32), for the GP = 9 B-spline basis.
+// On 32x32x2 tiles a [32 features x JC values] x [NOT tiles of 32] block costs JC*NOT*16 accumulators and 240 is the most the
+// allocator places, so 9 values need 5 + 4 windows with an idle tenth slot and 15 MFMAs per basis evaluation.  A 16x16 tile
+// costs 4 registers: [16 features x 3 values] x [12 tiles of 16] = 144 accumulators -- three windows of exactly three
+// values, 36 MFMAs (of 32 cycles) per basis evaluation, and room for two waves per SIMD.
+//   lane l: feature f = fb*16 + (l & 15) (A operand, one generated value per lane and MFMA), column (l & 15) of each
+//   16-column tile (B operand, one dY value per lane and tile), token 4*step + (l >> 4) for BOTH -- four tokens per step;
+//   D[row = feature 4*(l >> 4) + r][col = l & 15] in register r of the tile's accumulator.
+// Everything else as above: wave units (basis group, column-tile set, window, feature block) flattened over the grid,
+// compile-time window start, scalar wave index, operands prefetched PD blocks ahead, slabs + ordered reduce.
+// =============================================================================================
+template <int FAM, int GP, int JC, int NC>
+__global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg, int shared, int nbg) {
+    constexpr int NJC = (GP + JC - 1) / JC;
+    static_assert(GP % JC == 0 && (NJC == 3 || NJC == 1), "whole windows: three of three values (B-spline) or all nine (FastKAN)");
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr int UB = 1;                     // steps (of 4 tokens) per prefetch block
+    constexpr int PD = NC >= 12 ? 3 : 6;      // blocks in flight (twelve dY streams: four measured the same as three, at 255 registers)
+    const int lane = threadIdx.x & 63, l15 = lane & 15, tq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int units = nfb * nos * nbg * NJC;
+    const long long gw = (long long)blockIdx.x * 4 + wave;       // global wave index over (slab, unit), unit fastest
+    if (gw >= (long long)units * a.msplit) return;
+    const int u = (int)(gw % units), slab = (int)(gw / units);
+    const int fb = u % nfb, os = (u / nfb) % nos, jc = (u / (nfb * nos)) % NJC, bg = u / (nfb * nos * NJC);
+    const long long ms = (long long)slab * a.rows_per_split;
+    long long me = ms + a.rows_per_split;
+    if (me > a.M) me = a.M;
+    const int len = (int)(me - ms);
+    if (len <= 0) return;
+    const int otpg = a.O / 16;                // 16-column tiles per group
+    const int f = fb * 16 + l15;
+    const int gx = bg % a.xmod;
+    int tg[NC];                               // group of column tile i (or -1 past the last tile: recomputes tile 0, never stored)
+    int dyo[NC];                              // column of this lane in tile i, relative to a dY row
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int tt = os * NC + i;
+        const int ts = tt < tiles_per_bg ? tt : os * NC;
+        const int pj = ts / otpg;
+        const int g = shared ? pj * a.xmod + bg : bg;
+        tg[i] = tt < tiles_per_bg ? g : -1;
+        dyo[i] = g * a.O + (ts - pj * otpg) * 16 + l15;
+    }
+    const float* xbase = a.x + ms * a.ldx + (long long)gx * a.I;      // wave-uniform
+    const float* dybase = a.dy + ms * a.ldy;                          // wave-uniform
+    const int ldx32 = (int)a.ldx, ldy32 = (int)a.ldy;
+    const BasisArgs b = make_basis(a, bg);
+    // FastKAN: the spline path reads u = LayerNorm(x) -- a separate tensor, or (KANVIT_FLAG_FUSED_LN) rebuilt from x, the saved
+    // (mean, rstd) of the token's x slice (one 8-byte load per token, the same address in all 16 lanes of a token) and this
+    // lane's gamma / beta
+    const bool ln = RBF && a.ln;
+    const float* ubase = (RBF && !ln && a.u) ? a.u + ms * a.ldu + (long long)bg * a.I : xbase;
+    const int ldu32 = (RBF && !ln && a.u) ? (int)a.ldu : ldx32;
+    const float* stbase = ln ? a.stats + (ms * a.xmod + gx) * 2 : nullptr;
+    const int ldst = 2 * a.xmod;
+    float ln_g = 1.0f, ln_b = 0.0f;
+    if constexpr (RBF) {
+        if (ln) {
+            ln_g = b.bp[a.G + f];
+            ln_b = b.bp[a.G + a.I + f];
+        }
+    }
+
+    auto run = [&](auto j0c) {
+        constexpr int J0C = decltype(j0c)::value;
+        BasisGenP<FAM, JC, J0C> proto;
+        proto.prepare(b, f, J0C);
+        f32x4 acc[JC][NC];
+#pragma unroll
+        for (int j = 0; j < JC; ++j)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) acc[j][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float rx[PD][UB], rdy[PD][UB][NC];
+        float2 ru[RBF ? PD : 1][RBF ? UB : 1];      // FastKAN: u (in .x), or the token's (mean, rstd)
+        auto tok_of = [&](int blk, int t) -> int { return 4 * (blk * UB + t) + tq; };
+        auto load_block = [&](int q, int blk) {
+#pragma unroll
+            for (int t = 0; t < UB; ++t) {
+                int tk = tok_of(blk, t);
+                if (tk > len - 1) tk = len - 1;
+                rx[q][t] = xbase[tk * ldx32 + f];
+                if constexpr (RBF) {
+                    if (ln) ru[q][t] = *reinterpret_cast<const float2*>(stbase + tk * ldst);
+                    else ru[q][t].x = ubase[tk * ldu32 + f];
+                }
+                const int dyr = tk * ldy32;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) rdy[q][t][i] = dybase[dyr + dyo[i]];
+            }
+        };
+        const int nblk = (len + 4 * UB - 1) / (4 * UB);
+#pragma unroll
+        for (int q = 0; q < PD; ++q)
+            if (q < nblk) load_block(q, q);
+        // A block is copied out of the ring and its slot refilled BEFORE its MFMAs (prefetch distance PD blocks).  Reading the ring
+        // registers directly and refilling after the MFMAs saves NC + 1 moves per step but shortens the distance to PD - 1 blocks:
+        // measured slower (767 -> 812 us on the ViT-B q|k|v launch) -- at two waves per SIMD this kernel lives on its prefetch depth.
+        for (int blk0 = 0; blk0 < nblk; blk0 += PD) {
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                const int blk = blk0 + q;
+                if (blk < nblk) {
+                    float cx[UB], cu[UB], cdy[UB][NC];
+                    bool ok[UB];
+#pragma unroll
+                    for (int t = 0; t < UB; ++t) {
+                        ok[t] = tok_of(blk, t) < len;
+                        cx[t] = rx[q][t];
+                        cu[t] = 0.0f;
+                        if constexpr (RBF) cu[t] = ln ? (rx[q][t] - ru[q][t].x) * ru[q][t].y * ln_g + ln_b : ru[q][t].x;
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) cdy[t][i] = rdy[q][t][i];
+                    }
+                    if (blk + PD < nblk) load_block(q, blk + PD);
+#pragma unroll
+                    for (int t = 0; t < UB; ++t) {
+                        BasisGenP<FAM, JC, J0C> gen = proto;
+                        gen.init(cx[t], cu[t]);
+#pragma unroll
+                        for (int j = 0; j < JC; ++j) {
+                            const float av = ok[t] ? gen.next(j) : 0.0f;          // rows past the slab contribute nothing (JC selects, not NC)
+#pragma unroll
+                            for (int i = 0; i < NC; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // dW partial of this slab: row k = (fb*16 + 4*tq + r)*GP + J0C + j, 16 contiguous columns per row and tile
+        float* base = a.slab + (long long)slab * ((long long)a.groups * a.K * a.O);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (tg[i] < 0) continue;
+            float* gb = base + (long long)tg[i] * a.K * a.O + (dyo[i] - tg[i] * a.O);
+#pragma unroll
+            for (int j = 0; j < JC; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gb[((long long)(fb * 16 + 4 * tq + r) * GP + J0C + j) * a.O] = acc[j][i][r];
+        }
+    };
+    if (NJC == 1 || jc == 0) run(std::integral_constant<int, 0>{});
+    else if constexpr (NJC == 3) {
+        if (jc == 1) run(std::integral_constant<int, JC>{});
+        else run(std::integral_constant<int, 2 * JC>{});
+    }
+}
+
 // ordered sum of the msplit partial slabs (deterministic; no float atomics)
 __global__ __launch_bounds__(256) void kan_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                               long long total, int msplit) {
@@ -275,7 +424,21 @@ int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t
     return 0;
 }
 
+template <int FAM, int GP, int JC, int NC>
+int launch_bwd_weight_reg16(LayerArgs& a, const BwRegPlan& p, hipStream_t st) {
+    const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
+    dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
+    hipLaunchKernelGGL((kan_bwd_weight_reg16_kernel<FAM, GP, JC, NC>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+    KV_LAUNCH_CHECK("kan_bwd_weight_reg16_kernel");
+    return 0;
+}
+
 int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+    if (p.t16) {
+        if (bf || (family != KANVIT_BSPLINE && family != KANVIT_RBF)) return kv_fail(KANVIT_EINVAL, "internal: 16-row weight-gradient dispatch");
+        if (family == KANVIT_RBF) return launch_bwd_weight_reg16<KV_RBF, 9, 9, 4>(a, p, st);
+        return p.nt == 12 ? launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 12>(a, p, st) : launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 4>(a, p, st);
+    }
     switch (family) {
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
         case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
@@ -317,6 +480,47 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     else return p;
     if (d->I % 32 || d->O % 32 || d->M < 256) return p;
     const int nshare = d->groups / d->x_group_mod;
+    // B-spline (exact fp32): the 16-row-tile kernel -- three windows of three values x 12 (or 4) column tiles of 16, no idle
+    // slot, two waves per SIMD -- when the 16-column tiles of a basis group divide by 12 or 4 (q|k|v of a 64-wide head: 12)
+    // FastKAN (exact fp32): the same kernel with all nine values x 4 column tiles of 16 per wave (its q, k, v do not share u):
+    // 36 MFMAs per evaluation of the eight Gaussians + silu instead of 18
+    const bool bf16_mode = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
+    if (((fam == KANVIT_BSPLINE && p.njc == 2) || (fam == KANVIT_RBF && !bf16_mode)) && !kv_config().bw_no_t16) {
+        const int sh = (kv_share_ok(fam, d->flags) && nshare > 1) ? 1 : 0;
+        const int t16 = (sh ? nshare : 1) * (d->O / 16);
+        const int nc = (fam != KANVIT_RBF && t16 % 12 == 0) ? 12 : ((t16 % 4 == 0) ? 4 : 0);      // else: the 32-row kernel below
+        if (nc) {
+            p.t16 = 1;
+            p.shared = sh;
+            p.nbg = sh ? d->x_group_mod : d->groups;
+            p.tiles_per_bg = t16;
+            p.nfb = d->I / 16;
+            p.nt = nc;
+            p.njc = fam == KANVIT_RBF ? 1 : 3;
+            p.nos = t16 / nc;
+            const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
+            const long long slots = 8LL * N_CU;                   // two waves per SIMD
+            long long r = 1;
+            while (slots * r < units) ++r;
+            // the round count that wastes the fewest slots among r, r + 1 (e.g. 576 units: 3 slabs fill 84 % of one round, 7 slabs 98 % of two)
+            long long S = slots * r / units, S2 = slots * (r + 1) / units;
+            if (S2 * units * r > S * units * (r + 1) && S2 <= d->M / 64) { S = S2; }
+            const long long smax = d->M / 64;
+            if (S > smax) S = smax;
+            if (S < 1) S = 1;
+            if (S > 65535) return BwRegPlan{};
+            long long rps = (d->M + S - 1) / S;
+            rps = (rps + 15) / 16 * 16;
+            p.rows_per_slab = rps;
+            p.slabs = (int)((d->M + rps - 1) / rps);
+            long long ld = d->ldx > d->ldy ? d->ldx : d->ldy;
+            if (d->ldu > ld) ld = d->ldu;
+            if (rps * ld + ld >= (1LL << 29) || units > (1LL << 30)) return BwRegPlan{};
+            p.ws_bytes = p.slabs > 1 ? sizeof(float) * (size_t)p.slabs * d->groups * ((size_t)d->I * p.gp) * d->O : 0;
+            p.ok = true;
+            return p;
+        }
+    }
     p.shared = (kv_share_ok(fam, d->flags) && nshare > 1) ? 1 : 0;
     p.nbg = p.shared ? d->x_group_mod : d->groups;
     p.tiles_per_bg = (p.shared ? nshare : 1) * (d->O / 32);

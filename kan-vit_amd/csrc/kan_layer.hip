@@ -119,6 +119,7 @@ static void kv_config_load() {
     auto num = [](const char* n) { const char* v = getenv(n); return v ? atoi(v) : 0; };
     c.no_reg = flag("KANVIT_NO_REG");
     c.no_reg_bw = flag("KANVIT_NO_REG_BW");
+    c.bw_no_t16 = flag("KANVIT_BW_NO_T16");
     c.no_fast = flag("KANVIT_NO_FAST");
     c.no_pipe = flag("KANVIT_NO_PIPE");
     c.no_ws = flag("KANVIT_NO_WS");
@@ -134,8 +135,8 @@ static void kv_config_load() {
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
-             c.no_reg, c.no_reg_bw, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
+             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
+             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }

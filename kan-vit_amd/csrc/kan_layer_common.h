@@ -181,6 +181,7 @@ struct BwPlan {
 struct BwRegPlan {
     bool ok;
     int gp, nt, nfb, nos, tiles_per_bg, nbg, shared, slabs, njc;
+    int t16;              // 1: the 16-row-tile kernel (nt = 16-column tiles per wave, nfb = 16-feature blocks)
     long long rows_per_slab;
     size_t ws_bytes;
 };

@@ -40,6 +40,7 @@ static inline int kv_fail(int code, const char* fmt, ...) {
 struct KvConfig {
     int no_reg;          // KANVIT_NO_REG          register-form KAN kernels off (LDS-tile kernels everywhere)
     int no_reg_bw;       // KANVIT_NO_REG_BW       register-form weight gradient off
+    int bw_no_t16;       // KANVIT_BW_NO_T16       B-spline weight gradient on 32-row tiles (5 + 4 windows) instead of the 16-row-tile kernel
     int no_fast;         // KANVIT_NO_FAST         predicate-free variants of the LDS-tile kernels off
     int no_pipe;         // KANVIT_NO_PIPE         fp32 register kernels without the one-step-ahead LDS fragment prefetch (round-1 form)
     int no_ws;           // KANVIT_NO_WS           W-stationary bf16 forward off
