@@ -242,6 +242,16 @@ int kanvit_addln_bwd(int64_t M, int D, const float* xsum, const float* gamma, co
                      const float* dy, const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ---- ReLU backward + bias gradient of the feed-forward's first Linear in one pass ----------------
+ * The TransformerBlock's nn.Sequential(Linear, ReLU(inplace), Linear) (model.py:25-29): what autograd runs for the ReLU and
+ * for the first Linear's bias -- threshold_backward on the saved activation y, then a column sum of the result --
+ *     dh[m][n] = y[m][n] > 0 ? dy[m][n] : 0,      dbias[n] = sum_m dh[m][n]
+ * as one pass over [M, N] + an ordered reduce of per-row-band partial sums (deterministic).  dh may alias dy.
+ * Row-major contiguous [M][N] fp32, N % 4 == 0, 16-byte aligned pointers; workspace: kanvit_relu_bwd_bias_workspace(M, N). */
+size_t kanvit_relu_bwd_bias_workspace(int64_t M, int N);
+int kanvit_relu_bwd_bias(int64_t M, int N, const float* dy, const float* y, float* dh, float* dbias, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ---- three-term bf16 split image (opt-in "bf16x3" feed-forward mode, kanvit/dense.py) --------------------------------
  * v = hi + lo, hi = bf16(v), lo = bf16(v - hi).  Writes out[M][3K] (bf16) = [hi|hi|lo] (pattern 0) or [hi|lo|hi]
  * (pattern 1) of  v = x (+ bias[K]) (ReLU if relu) (zeroed where mask_hi[m][k] <= 0, a bf16 image with row stride

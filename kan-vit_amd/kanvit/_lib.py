@@ -85,6 +85,8 @@ SYMBOLS = {
     "kanvit_addln_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "kanvit_addln_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
     "kanvit_addln_bwd": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kanvit_relu_bwd_bias_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
+    "kanvit_relu_bwd_bias": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_split3_bf16": (C.c_int, [C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int64, _P, C.c_int, _P]),
 }
 for _f in FAMILY_NAMES:
@@ -125,11 +127,13 @@ def py_switches() -> dict:
     library's own (never on the launch path) and echoed by active_config(), so a bench line states what it timed:
       ff           KANVIT_FF=bf16x3       opt-in three-term bf16 split-product feed-forward (default fp32)
       no_ff_small  KANVIT_NO_FF_SMALL     stock GEMMs instead of the fused small feed-forward (csrc/ff_small.hip)
-      no_lnff      KANVIT_NO_LNFF         separate add+LayerNorm in front of the fused small feed-forward"""
+      no_lnff      KANVIT_NO_LNFF         separate add+LayerNorm in front of the fused small feed-forward
+      no_ff_epi    KANVIT_NO_FF_EPILOGUE  stock threshold_backward + sum(0) instead of the fused ReLU-mask + bias-gradient pass"""
     global _py_switches
     if _py_switches is None:
         _py_switches = {"ff": os.environ.get("KANVIT_FF", ""), "no_ff_small": int(bool(os.environ.get("KANVIT_NO_FF_SMALL"))),
-                        "no_lnff": int(bool(os.environ.get("KANVIT_NO_LNFF")))}
+                        "no_lnff": int(bool(os.environ.get("KANVIT_NO_LNFF"))),
+                        "no_ff_epi": int(bool(os.environ.get("KANVIT_NO_FF_EPILOGUE")))}
     return _py_switches
 
 
@@ -138,7 +142,7 @@ def active_config() -> str:
     library's (KvConfig) followed by the Python-side ones (py_switches)."""
     ps = py_switches()
     alt = f" lib={LIB_PATH}" if os.environ.get("KANVIT_LIB") else ""
-    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']}" + alt
+    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']} py_no_ff_epi={ps['no_ff_epi']}" + alt
 
 
 def reload_config() -> str:

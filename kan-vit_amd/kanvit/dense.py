@@ -68,7 +68,12 @@ class _DenseFn(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             dy = dy.contiguous().to(xc.dtype)
             if ctx.relu:
-                dy = torch.ops.aten.threshold_backward(dy, y, 0)
+                if (dy.is_cuda and dy.dtype == torch.float32 and y.dtype == torch.float32 and y.is_contiguous() and dy.shape[1] % 4 == 0
+                        and ctx.has_bias and ctx.needs_input_grad[2] and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
+                        and not _lib.py_switches()["no_ff_epi"]):
+                    dy, db = _relu_bwd_bias(dy, y)      # ReLU mask + bias gradient in one pass (csrc/ff_epilogue.hip)
+                else:
+                    dy = torch.ops.aten.threshold_backward(dy, y, 0)
             if ctx.needs_input_grad[0]:
                 dx = (dy @ wc).to(xdt)
             if ctx.needs_input_grad[1]:
@@ -81,9 +86,28 @@ class _DenseFn(torch.autograd.Function):
                 else:
                     dw = dy.t() @ xc
                 dw = dw.to(wdt)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if db is not None:
+                db = db.to(wdt)
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
                 db = (dy.sum(0, dtype=torch.float32) if dy.dtype in _HALF else dy.sum(0)).to(wdt)
         return dx, dw, db, None
+
+
+def _relu_bwd_bias(dy: torch.Tensor, y: torch.Tensor):
+    """(dy masked by y > 0, column sums of the result): kanvit_relu_bwd_bias -- what threshold_backward + sum(0) compute in two
+    passes over [M, 4d].  The masked gradient goes to a fresh tensor (the incoming dy may be shared with other consumers)."""
+    import ctypes as C
+    from . import ops
+    M, N = dy.shape
+    L = _lib.lib()
+    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    out = torch.empty_like(dy)
+    with torch.cuda.device(dy.device):
+        nbytes = int(L.kanvit_relu_bwd_bias_workspace(M, N))
+        ws = ops._workspace(nbytes, dy.device)
+        _lib.check(L.kanvit_relu_bwd_bias(M, N, ops._ptr(dy), ops._ptr(y), ops._ptr(out), ops._ptr(db), ops._ptr(ws), C.c_size_t(nbytes),
+                                          ops._stream()), "kanvit_relu_bwd_bias")
+    return out, db
 
 
 def dense(x: torch.Tensor, linear: torch.nn.Linear, relu: bool = False) -> torch.Tensor:

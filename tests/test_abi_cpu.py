@@ -125,7 +125,7 @@ def test_switches_are_read_once_and_reported(lib, monkeypatch):
     monkeypatch.delenv("KANVIT_NO_REG")
     assert _lib.reload_config() == base
     # the Python-side switches (kanvit/dense.py) follow the same rule and are part of the same report
-    assert "py_ff=default" in base and "py_no_ff_small=0" in base and "py_no_lnff=0" in base
+    assert "py_ff=default" in base and "py_no_ff_small=0" in base and "py_no_lnff=0" in base and "py_no_ff_epi=0" in base
     monkeypatch.setenv("KANVIT_FF", "bf16x3")
     monkeypatch.setenv("KANVIT_NO_LNFF", "1")
     assert _lib.active_config() == base
@@ -223,3 +223,7 @@ def test_assembly_helpers_validate_arguments_without_a_gpu(lib):
         assert lib.kanvit_split3_bf16(4, K, p, None, 0, None, 0, p, 0, None) != 0
         assert b"kanvit_split3_bf16" in lib.kanvit_last_error()
     assert lib.kanvit_split3_bf16(0, 16, p, None, 0, None, 0, p, 0, None) == 0
+    assert lib.kanvit_relu_bwd_bias(4, 6, p, p, p, p, p, 1 << 20, None) != 0          # N % 4
+    assert b"kanvit_relu_bwd_bias" in lib.kanvit_last_error()
+    assert lib.kanvit_relu_bwd_bias(4, 8, p, p, p, p, None, 0, None) != 0             # workspace missing
+    assert lib.kanvit_relu_bwd_bias_workspace(25216, 3072) % 16 == 0 and lib.kanvit_relu_bwd_bias_workspace(0, 8) == 0

@@ -7,7 +7,7 @@ N=$1; shift
 O=$R/kan-vit_amd/kanvit/_ab; mkdir -p $O/obj_$N
 cd $R/kan-vit_amd/csrc
 pids=()
-for f in kan_tile kan_fwd_reg kan_fwd_reg_bf16 kan_bwd_input_reg kan_bwd_input_reg_bf16 kan_bwd_weight_reg kan_layer attention addln split3 ff_small kan_tiny; do
+for f in kan_tile kan_fwd_reg kan_fwd_reg_bf16 kan_bwd_input_reg kan_bwd_input_reg_bf16 kan_bwd_weight_reg kan_layer attention addln split3 ff_small ff_epilogue kan_tiny; do
   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -fno-finite-math-only -fvisibility=hidden -I ../../include "$@" -c $f.hip -o $O/obj_$N/$f.o &
   pids+=($!)
 done
