@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define KANVIT_ABI_VERSION 5
+#define KANVIT_ABI_VERSION 6
 
 /* error codes */
 #define KANVIT_OK 0
@@ -66,6 +66,14 @@ extern "C" {
 #define KANVIT_FLAG_SHARED_BPARAMS 4 /* groups that read the same x columns (q, k, v of a head) also have identical
                                     basis parameters, so one basis tile may serve all of them (as for the
                                     parameter-free families).  Honoured for BSPLINE.                                */
+
+#define KANVIT_FLAG_SINE_DFREQ 16 /* SINE, kanvit_layer_bwd_weight only: the generated operand is x * cos(x f_g + p_ig) instead of
+                                    sin(x f_g + p_ig), so the result is Q[(i,g)][o] = sum_m dy[m][o] x[m][i] cos(...) and
+                                    d loss / d freq_g = sum_{i,o} w[(i,g)][o] Q[(i,g)][o] -- the frequency gradient of a layer
+                                    whose INPUT gradient nobody needs (the patch embedding: its input is the image) at the
+                                    cost of a second weight-gradient pass instead of the slower input-gradient contraction
+                                    (models/sinekan.py:81-91; freq is trainable, sinekan.py:60).  Shapes the register
+                                    weight-gradient kernels do not cover are refused (EINVAL).                          */
 
 /* basis families: phi_g(x) generated on the fly, never stored in HBM */
 #define KANVIT_LINEAR 0   /* phi = x                               nn.Linear in attention.py:136-142           */
@@ -145,6 +153,9 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
                            const float* bparams, const float* dy, float* dx, float* du, float* dparam,
                            void* workspace, size_t workspace_bytes, void* stream);
 int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d);
+/* 1 if KANVIT_FLAG_SINE_DFREQ may be set for kanvit_layer_bwd_weight on this layer (SINE, a shape the register weight-gradient
+ * kernels cover), else 0.  The flag is refused by kanvit_layer_fwd and kanvit_layer_bwd_input.  (ABI >= 6) */
+int kanvit_layer_sine_dfreq_ok(const kanvit_layer_desc* d);
 
 /* ---- backward w.r.t. the packed weights ---------------------------------------------------
  * dw[g][i*GP+j][o] = sum_m phi_j(x[m, ...i]) * dy[m, g*O+o]; split over row ranges into

@@ -19,6 +19,7 @@
 #define KV_RBF 3
 #define KV_SINE 4
 #define KV_FOURIER 5
+#define KV_SINE_DF 6      // internal (not an ABI family): SINE's frequency-derivative operand x * cos(x f + p), weight-gradient kernels only (KANVIT_FLAG_SINE_DFREQ)
 
 #define KV_MAX_KNOTS 40   // generic B-spline path: grid_size + 2*order + 1 <= 40
 
@@ -410,8 +411,9 @@ __device__ __forceinline__ void basis_bwd(const BasisArgs& b, float xv, float uv
 // ---------------------------------------------------------------------------------------------
 template <int FAM, int GP, int J0C = -1>      // J0C >= 0: the window start is a compile-time constant (B-spline / RBF windows)
 struct BasisGenP {
-    static constexpr int NC0 = (FAM == KV_SINE) ? GP : 1;         // RBF: only the first centre (uniform grid, kv_rbf8)
-    static constexpr int NC1 = (FAM == KV_SINE) ? GP : 1;
+    static constexpr bool SINE_ = (FAM == KV_SINE || FAM == KV_SINE_DF);
+    static constexpr int NC0 = SINE_ ? GP : 1;         // RBF: only the first centre (uniform grid, kv_rbf8)
+    static constexpr int NC1 = SINE_ ? GP : 1;
     float c0[NC0], c1[NC1];
     float g0, ih, inv_h;
     int nkm1, G;
@@ -430,7 +432,7 @@ struct BasisGenP {
         G = b.G;
         inv_h = b.inv_h;
         j0w = j0;
-        if constexpr (FAM == KV_SINE) {
+        if constexpr (SINE_) {
 #pragma unroll
             for (int j = 0; j < GP; ++j) {
                 c0[j] = b.bp[j0 + j];
@@ -498,6 +500,8 @@ struct BasisGenP {
             sk = sk * c1r + ck * s1;
             ck = cn;
             return v;
+        } else if constexpr (FAM == KV_SINE_DF) {   // d sin(x f + p) / d f = x cos(x f + p): same argument arithmetic as BasisDGen<KV_SINE>
+            return x * kv_cos(__fadd_rn(__fmul_rn(x, c0[j < NC0 ? j : 0]), c1[j < NC1 ? j : 0]));
         } else {   // SINE
             return kv_sin(__fadd_rn(__fmul_rn(x, c0[j < NC0 ? j : 0]), c1[j < NC1 ? j : 0]));
         }

@@ -446,6 +446,10 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
             return p.nt == 3 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 3, 5, false>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 5, false>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:
+            if (a.flags & KANVIT_FLAG_SINE_DFREQ) {      // the x * cos operand (d loss / d freq through a weight-gradient pass; kanvit.h)
+                if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE_DF, 28, 4, 4>(a, p, bf, st);
+                return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE_DF, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE_DF, 5, 2>(a, p, bf, st);
+            }
             if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE, 28, 4, 4>(a, p, bf, st);
             return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE, 5, 2>(a, p, bf, st);
         case KANVIT_FOURIER: return launch_bwd_weight_reg<KV_FOURIER, 56, 4, 4>(a, p, bf, st);

@@ -40,6 +40,8 @@ int validate(const kanvit_layer_desc* d, const char* who) {
         if (d->bparam_stride < (int64_t)d->I * nk) return kv_fail(KANVIT_EINVAL, "%s: bparam_stride too small", who);
     }
     if (d->family == KANVIT_RBF && d->bparam_stride < d->G) return kv_fail(KANVIT_EINVAL, "%s: bparam_stride too small", who);
+    if ((d->flags & KANVIT_FLAG_SINE_DFREQ) && d->family != KANVIT_SINE)
+        return kv_fail(KANVIT_EINVAL, "%s: KANVIT_FLAG_SINE_DFREQ is a SINE flag", who);
     if (d->flags & KANVIT_FLAG_FUSED_LN) {
         if (d->family != KANVIT_RBF) return kv_fail(KANVIT_EINVAL, "%s: KANVIT_FLAG_FUSED_LN is an RBF (FastKAN) flag", who);
         if (d->bparam_stride < (int64_t)d->G + 2 * (int64_t)d->I)
@@ -173,6 +175,7 @@ size_t kanvit_layer_fwd_workspace(const kanvit_layer_desc* d) {
 int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u, const float* w, const float* bparams,
                      const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = validate(d, "kanvit_layer_fwd")) return rc;
+    if (d->flags & KANVIT_FLAG_SINE_DFREQ) return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: KANVIT_FLAG_SINE_DFREQ is a kanvit_layer_bwd_weight flag");
     if (d->M == 0) return 0;
     if (!x || !w || !y) return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: null x/w/y");
     if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_layer_fwd: family %d needs bparams", d->family);
@@ -286,6 +289,12 @@ int kanvit_patch_embed_fwd(const kanvit_layer_desc* d, const kanvit_patch_desc* 
     return rc;
 }
 
+int kanvit_layer_sine_dfreq_ok(const kanvit_layer_desc* d) {
+    if (!d || d->family != KANVIT_SINE || gp_of(d) < 1 || d->groups < 1 || d->x_group_mod < 1 || d->I < 1 || d->O < 1 || d->M < 1) return 0;
+    if (kv_tiny_ok(d)) return 0;
+    return plan_bwd_weight_reg(d).ok ? 1 : 0;
+}
+
 int64_t kanvit_layer_dparam_tiles(const kanvit_layer_desc* d) {
     if (!d || d->family != KANVIT_SINE) return 0;
     return (d->M + BM - 1) / BM;
@@ -310,6 +319,7 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
     if (!x || !w || !dy || !dx) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: null x/w/dy/dx");
     if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: family %d needs bparams", d->family);
     if (d->family == KANVIT_SINE && !dparam) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: SINE needs dparam");
+    if (d->flags & KANVIT_FLAG_SINE_DFREQ) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: KANVIT_FLAG_SINE_DFREQ is a kanvit_layer_bwd_weight flag");
     if (d->family == KANVIT_RBF && (u || du) && d->ldu < (int64_t)d->groups * d->I)
         return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_input: ldu < groups*I");
     if (d->family == KANVIT_SINE && (d->groups / d->x_group_mod) * 4 * d->G > 4096)
@@ -383,6 +393,8 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
     const size_t need = kanvit_layer_bwd_weight_workspace(d);
     if (need > 0 && (!workspace || workspace_bytes < need))
         return kv_fail(KANVIT_ENOMEM, "kanvit_layer_bwd_weight: workspace %zu bytes < required %zu", workspace_bytes, need);
+    if ((d->flags & KANVIT_FLAG_SINE_DFREQ) && !kanvit_layer_sine_dfreq_ok(d))
+        return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: KANVIT_FLAG_SINE_DFREQ needs the register weight-gradient kernel (shape)");
     if (kv_tiny_ok(d)) {
         hipStream_t st = (hipStream_t)stream;
         KvTinyArgs t = tiny_args(d);

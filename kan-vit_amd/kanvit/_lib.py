@@ -21,6 +21,7 @@ FLAG_BF16_MFMA = 1
 FLAG_UNIFORM_KNOTS = 2
 FLAG_SHARED_BPARAMS = 4
 FLAG_FUSED_LN = 8
+FLAG_SINE_DFREQ = 16
 FAMILY_NAMES = ["linear", "cheby", "bspline", "rbf", "sine", "fourier"]
 
 
@@ -76,6 +77,7 @@ SYMBOLS = {
     "kanvit_layer_fwd": (C.c_int, _LAYER_FWD),
     "kanvit_layer_bwd_input": (C.c_int, _LAYER_BWD_IN),
     "kanvit_layer_dparam_tiles": (C.c_int64, [C.POINTER(LayerDesc)]),
+    "kanvit_layer_sine_dfreq_ok": (C.c_int, [C.POINTER(LayerDesc)]),
     "kanvit_layer_bwd_weight_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_bwd_weight": (C.c_int, _LAYER_BWD_W),
     "kanvit_patch_embed_fwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(PatchDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -113,7 +115,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.kanvit_abi_version() != 5:
+        if handle.kanvit_abi_version() != 6:
             raise KanvitError("libkanvit.so ABI version mismatch")
         _lib = handle
     return _lib
@@ -128,12 +130,14 @@ def py_switches() -> dict:
       ff           KANVIT_FF=bf16x3       opt-in three-term bf16 split-product feed-forward (default fp32)
       no_ff_small  KANVIT_NO_FF_SMALL     stock GEMMs instead of the fused small feed-forward (csrc/ff_small.hip)
       no_lnff      KANVIT_NO_LNFF         separate add+LayerNorm in front of the fused small feed-forward
-      no_ff_epi    KANVIT_NO_FF_EPILOGUE  stock threshold_backward + sum(0) instead of the fused ReLU-mask + bias-gradient pass"""
+      no_ff_epi    KANVIT_NO_FF_EPILOGUE  stock threshold_backward + sum(0) instead of the fused ReLU-mask + bias-gradient pass
+      no_dfreq_w   KANVIT_NO_DFREQ_W      SineKAN d loss / d freq always through the input-gradient kernel (ops._kan_backward)"""
     global _py_switches
     if _py_switches is None:
         _py_switches = {"ff": os.environ.get("KANVIT_FF", ""), "no_ff_small": int(bool(os.environ.get("KANVIT_NO_FF_SMALL"))),
                         "no_lnff": int(bool(os.environ.get("KANVIT_NO_LNFF"))),
-                        "no_ff_epi": int(bool(os.environ.get("KANVIT_NO_FF_EPILOGUE")))}
+                        "no_ff_epi": int(bool(os.environ.get("KANVIT_NO_FF_EPILOGUE"))),
+                        "no_dfreq_w": int(bool(os.environ.get("KANVIT_NO_DFREQ_W")))}
     return _py_switches
 
 
@@ -142,7 +146,7 @@ def active_config() -> str:
     library's (KvConfig) followed by the Python-side ones (py_switches)."""
     ps = py_switches()
     alt = f" lib={LIB_PATH}" if os.environ.get("KANVIT_LIB") else ""
-    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']} py_no_ff_epi={ps['no_ff_epi']}" + alt
+    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']} py_no_ff_epi={ps['no_ff_epi']} py_no_dfreq_w={ps['no_dfreq_w']}" + alt
 
 
 def reload_config() -> str:

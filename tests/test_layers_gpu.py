@@ -94,6 +94,56 @@ def test_against_oracle_ragged_shapes(fam, shape):
         assert rel_err(gp[k], g) < GRAD_TOL, (fam, shape, k, rel_err(gp[k], g))
 
 
+@pytest.mark.parametrize("shape", [(7, 5, 3), (300, 192, 64), (513, 48, 200), (1100, 64, 64), (2048, 768, 96), (129, 64, 64)])
+def test_sine_frequency_gradient_without_input_gradient(shape, monkeypatch):
+    """x that needs no gradient (the patch embedding's input is the image): d loss / d freq comes from a second weight-gradient pass
+    over the operand x cos(x f + p) (KANVIT_FLAG_SINE_DFREQ, ops._kan_backward) instead of the input-gradient kernel -- the same
+    number within fp32 summation order, and within 1e-4 of the float64 oracle (models/sinekan.py:81-91, freq trainable :60)."""
+    from kanvit import _lib, ops
+    m, i, o = shape
+    torch.manual_seed(m + i)
+    layer = make_layer("sine", i, o, big=(i <= 48 or i == 768)).to(DEV)
+    x = (torch.randn(m, i) * 1.5)
+    _, _, gpo = oracle_run(layer, x)
+    res = {}
+    for name, env, needs_x in (("weight_pass", None, False), ("input_kernel", "1", False), ("with_dx", None, True)):
+        if env:
+            monkeypatch.setenv("KANVIT_NO_DFREQ_W", env)
+        else:
+            monkeypatch.delenv("KANVIT_NO_DFREQ_W", raising=False)
+        _lib.reload_config()
+        layer.zero_grad()
+        xg = x.to(DEV).requires_grad_(needs_x)
+        layer(xg).square().sum().backward()
+        res[name] = {k: v.grad.clone().cpu() for k, v in layer.named_parameters() if v.grad is not None}
+    monkeypatch.delenv("KANVIT_NO_DFREQ_W", raising=False)
+    _lib.reload_config()
+    for name, gp in res.items():
+        assert set(gp) == set(gpo), (name, set(gp) ^ set(gpo))
+        for k, g in gpo.items():
+            assert rel_err(gp[k], g) < GRAD_TOL, (shape, name, k, rel_err(gp[k], g))
+    # the two routes are different sums of the same products; amplitudes / bias do not depend on the route at all
+    assert rel_err(res["weight_pass"]["freq"], res["input_kernel"]["freq"]) < 2e-5
+    for k in ("amplitudes", "bias"):
+        assert torch.equal(res["weight_pass"][k], res["input_kernel"][k]), k
+    assert torch.equal(res["input_kernel"]["freq"], res["with_dx"]["freq"])      # same kernel whether or not dx is kept
+
+
+def test_sine_dfreq_flag_is_refused_elsewhere():
+    import ctypes as C
+    from kanvit import _lib
+    L = _lib.lib()
+    d = _lib.LayerDesc(4, 1, 1, 64, 64, 4, 0, 0, 0.0, _lib.FLAG_SINE_DFREQ, 256, 64, 64, 64, 4 + 64 * 4, 0.0, 0)
+    assert L.kanvit_layer_sine_dfreq_ok(C.byref(d)) == 1
+    buf = torch.zeros(64 * 64 * 4 + 4096, device=DEV)
+    p = C.c_void_p(buf.data_ptr())
+    assert L.kanvit_layer_fwd(C.byref(d), p, None, p, p, None, p, None, 0, None) != 0 and b"bwd_weight flag" in L.kanvit_last_error()
+    assert L.kanvit_layer_bwd_input(C.byref(d), p, None, p, p, p, p, None, p, None, 0, None) != 0 and b"bwd_weight flag" in L.kanvit_last_error()
+    d2 = _lib.LayerDesc(1, 1, 1, 64, 64, 4, 0, 0, 0.0, _lib.FLAG_SINE_DFREQ, 256, 64, 64, 64, 0, 0.0, 0)
+    assert L.kanvit_layer_sine_dfreq_ok(C.byref(d2)) == 0
+    assert L.kanvit_layer_bwd_weight(C.byref(d2), p, None, None, p, p, None, 0, None) != 0 and b"SINE flag" in L.kanvit_last_error()
+
+
 def test_non_default_spline_configuration():
     """grid_size / spline_order other than (5, 3) take the runtime-sized B-spline path."""
     from models.effkan import KANLinear
