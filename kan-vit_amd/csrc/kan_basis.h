@@ -135,9 +135,11 @@ __device__ __forceinline__ float kv_cos(float x) {
     return kv_sin_poly(r, k);
 }
 
-__device__ __forceinline__ float kv_silu(float x) { return x / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (11 instructions): silu is evaluated once per (row, feature) in the
+// B-spline and FastKAN kernels, which are bound by exactly this VALU work; 2 ulp of a value of order 1 against the 1e-4 parity bound.
+__device__ __forceinline__ float kv_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float kv_dsilu(float x) {
-    const float s = 1.0f / (1.0f + __expf(-x));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
     return s * (1.0f + x * (1.0f - s));
 }
 
@@ -534,8 +536,16 @@ __device__ __forceinline__ void basis_bwd_sine_reg(const BasisArgs& b, float xv,
 // the register-operand forward kernel, where every lane feeds its MFMA A operand directly (no LDS basis tile), so the
 // values must come out one at a time without runtime-indexed register arrays.
 // ---------------------------------------------------------------------------------------------
-template <int FAM>
+// GC >= 0: the number of grid functions G is a compile-time constant (register kernels with a compile-time basis size: RBF / BSPLINE
+// GP - 1 with the base column host-checked, FOURIER GP / 2, SINE GP).  With a runtime G every `j >= G` below is a wave-uniform
+// BRANCH around its own copy of the silu code -- nine copies and nine branches per feature in the unrolled kernels (the FastKAN
+// bf16 forward ran 34 VALU instructions per MFMA, profiles/r03_sq_pmc_fast_vits_bf16.md).
+constexpr int kv_gc(int fam, int gp) {
+    return gp <= 0 ? -1 : (fam == KV_RBF || fam == KV_BSPLINE) ? gp - 1 : (fam == KV_FOURIER ? gp / 2 : (fam == KV_SINE ? gp : -1));
+}
+template <int FAM, int GC = -1>
 struct BasisGen {
+    __device__ __forceinline__ int gcount() const { return GC >= 0 ? GC : G; }
     float x, u, t, p0, p1, c1, s1, ck, sk;
     float pr[(FAM == KV_RBF) ? 8 : 1];      // RBF (uniform grid, host-checked): kv_rbf8
     float bv[4];
@@ -579,16 +589,16 @@ struct BasisGen {
             p1 = p2;
             return p2;
         } else if constexpr (FAM == KV_BSPLINE) {
-            if (j >= G) return kv_silu(x);
+            if (j >= gcount()) return kv_silu(x);
             return kv_bsel4(j0, j, bv);
         } else if constexpr (FAM == KV_RBF) {
-            if (j >= G) return kv_silu(x);
+            if (j >= gcount()) return kv_silu(x);
             return kv_sel8(pr, j);
         } else if constexpr (FAM == KV_SINE) {
-            return kv_sin(__fadd_rn(__fmul_rn(x, bp[j]), bp[G + (long long)i * G + j]));
+            return kv_sin(__fadd_rn(__fmul_rn(x, bp[j]), bp[gcount() + (long long)i * gcount() + j]));
         } else {   // FOURIER: cos(k x) for j < G, then sin(k x)
             if (j == 0) return c1;
-            if (j == G) {
+            if (j == gcount()) {
                 ck = c1;
                 sk = s1;
                 return s1;
@@ -596,15 +606,16 @@ struct BasisGen {
             const float cn = ck * c1 - sk * s1;
             sk = sk * c1 + ck * s1;
             ck = cn;
-            return j < G ? ck : sk;
+            return j < gcount() ? ck : sk;
         }
     }
 };
 
 
 // Derivative generator: next(j) = d phi_j / d(input) for j = 0 .. GP-1 in order (RBF: d/du for j < G, d silu/dx for j = G).
-template <int FAM>
+template <int FAM, int GC = -1>
 struct BasisDGen {
+    __device__ __forceinline__ int gcount() const { return GC >= 0 ? GC : G; }
     float x, u, t, sech2, u0, u1, c1, s1, ck, sk, inv_h;
     float pr[(FAM == KV_RBF) ? 8 : 1];
     float lastc;   // SINE: cos(x f_j + p_ij) of the last next() (the caller needs it for d loss / d freq)
@@ -651,17 +662,17 @@ struct BasisDGen {
             u1 = u2;
             return r;
         } else if constexpr (FAM == KV_BSPLINE) {
-            if (j >= G) return kv_dsilu(x);
+            if (j >= gcount()) return kv_dsilu(x);
             return kv_bsel4(j0, j, dv);
         } else if constexpr (FAM == KV_RBF) {
-            if (j >= G) return kv_dsilu(x);
+            if (j >= gcount()) return kv_dsilu(x);
             return kv_sel8(pr, j) * (-2.0f * (t - (float)j) * inv_h);
         } else if constexpr (FAM == KV_SINE) {      // d sin(x f + p)/dx = f cos(x f + p)
             const float f = bp[j];
-            lastc = kv_cos(__fadd_rn(__fmul_rn(x, f), bp[G + (long long)i * G + j]));
+            lastc = kv_cos(__fadd_rn(__fmul_rn(x, f), bp[gcount() + (long long)i * gcount() + j]));
             return lastc * f;
         } else if constexpr (FAM == KV_FOURIER) {   // d cos(kx) = -k sin(kx) for j < G, d sin(kx) = k cos(kx) after
-            if (j == G) {
+            if (j == gcount()) {
                 ck = c1;
                 sk = s1;
             } else if (j != 0) {
@@ -669,8 +680,8 @@ struct BasisDGen {
                 sk = sk * c1 + ck * s1;
                 ck = cn;
             }
-            const float kf = (float)((j < G ? j : j - G) + 1);
-            return j < G ? -kf * sk : kf * ck;
+            const float kf = (float)((j < gcount() ? j : j - gcount()) + 1);
+            return j < gcount() ? -kf * sk : kf * ck;
         } else {
             return 0.0f;                            // SINE is not handled by the register kernels (dfreq reduction)
         }

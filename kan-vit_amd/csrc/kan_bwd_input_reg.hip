@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
             }
 #pragma unroll
             for (int j = 0; j < FPH; ++j) {
-                BasisDGen<FAM> gen;
+                BasisDGen<FAM, kv_gc(FAM, GP)> gen;
                 gen.init(b, xv[j], RBF ? uvv[j] : 0.0f, ci * IC + hf * FPH + j);
                 float dsum = 0.0f, usum = 0.0f;
 #pragma unroll
@@ -284,7 +284,7 @@ int try_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
     if constexpr (FAM == KV_LINEAR) { if (a.GP == 1) return launch_bwd_input_reg<FAM, 1, 2>(a, st); }
     if constexpr (FAM == KV_CHEBY) { if (a.GP == 5) return launch_bwd_input_reg<FAM, 5, 5>(a, st); }
     if constexpr (FAM == KV_BSPLINE) {
-        if (a.GP == 9 && (a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3) return launch_bwd_input_reg<FAM, 9, 5>(a, st);
+        if (a.GP == 9 && a.has_base && (a.flags & KANVIT_FLAG_UNIFORM_KNOTS) && a.order == 3) return launch_bwd_input_reg<FAM, 9, 5>(a, st);
     }
     if constexpr (FAM == KV_RBF) { if (a.GP == 9 && a.has_base && kv_rbf_reg_ok(a.flags, a.G)) return launch_bwd_input_reg<FAM, 9, 5>(a, st); }
     if constexpr (FAM == KV_FOURIER) { if (a.GP == 56) return launch_bwd_input_reg<FAM, 56, 7>(a, st); }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, FAM == KV_SINE ? 1 : 2) void kan_bwd_input_reg
             }
 #pragma unroll
             for (int j = 0; j < FPH; ++j) {
-                BasisDGen<FAM> gen;
+                BasisDGen<FAM, kv_gc(FAM, GP)> gen;
                 gen.init(b, xv[j], RBF ? uvv[j] : 0.0f, ci * IC + hf * FPH + j);
                 float dsum = 0.0f, usum = 0.0f;
 #pragma unroll
@@ -302,7 +302,7 @@ BwdRegBf16Plan plan_bwd_input_reg_bf16(const kanvit_layer_desc* d) {
     const int fam = d->family;
     if (fam == KANVIT_LINEAR && p.gp == 1) p.kt = 2;
     else if (fam == KANVIT_CHEBY && p.gp == 5) p.kt = 5;
-    else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) p.kt = 5;
+    else if (fam == KANVIT_BSPLINE && p.gp == 9 && d->has_base && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) p.kt = 5;
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.kt = 5;
     else if (fam == KANVIT_SINE && p.gp == 4) p.kt = 4;        // the per-head mappings (attention.py:140)
     else if (fam == KANVIT_SINE && p.gp == 28) p.kt = 7;       // the G = 28 patch embedding (model.py:72)

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
             float phi[VH];
 #pragma unroll
             for (int j = 0; j < ICH; ++j) {
-                BasisGen<FAM> gen;
+                BasisGen<FAM, kv_gc(FAM, GPC)> gen;       // compile-time G: one silu per feature, no branch per value (host-checked has_base)
                 gen.init(b, xc[j], uc[j], c * IC + hf * ICH + j);
 #pragma unroll
                 for (int g = 0; g < GPC; ++g) phi[j * GPC + g] = gen.next(g);
@@ -262,11 +262,11 @@ int launch_fwd_reg_ich(const LayerArgs& a, int ich, size_t lds, hipStream_t st) 
         if (ich == 4) {
             if constexpr (FAM == KV_LINEAR) { if (a.GP == 1) return launch_fwd_reg<FAM, NT, NSH, 4, 1>(a, lds, st); }
             if constexpr (FAM == KV_CHEBY) { if (a.GP == 5) return launch_fwd_reg<FAM, NT, NSH, 4, 5>(a, lds, st); }
-            if constexpr (FAM == KV_BSPLINE || FAM == KV_RBF) { if (a.GP == 9) return launch_fwd_reg<FAM, NT, NSH, 4, 9>(a, lds, st); }
+            if constexpr (FAM == KV_BSPLINE || FAM == KV_RBF) { if (a.GP == 9 && a.has_base) return launch_fwd_reg<FAM, NT, NSH, 4, 9>(a, lds, st); }
             if constexpr (FAM == KV_SINE) { if (a.GP == 4) return launch_fwd_reg<FAM, NT, NSH, 4, 4>(a, lds, st); }
         }
         if (ich == 2) {     // GP = 9 (B-spline, FastKAN): eight features x 9 rows x three projections overflow the W staging registers
-            if constexpr (FAM == KV_BSPLINE || FAM == KV_RBF) { if (a.GP == 9) return launch_fwd_reg<FAM, NT, NSH, 2, 9>(a, lds, st); }
+            if constexpr (FAM == KV_BSPLINE || FAM == KV_RBF) { if (a.GP == 9 && a.has_base) return launch_fwd_reg<FAM, NT, NSH, 2, 9>(a, lds, st); }
         }
         if (ich == 1) {
             if constexpr (FAM == KV_SINE) { if (a.GP == 28) return launch_fwd_reg<FAM, NT, NSH, 1, 28>(a, lds, st); }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
             load_x(c + 1);
         }
         const unsigned short* wp = W_s + (size_t)(c & 1) * WSZ + ((size_t)hf * WROW + l31) * 8;
-        BasisGen<FAM> gen;
+        BasisGen<FAM, kv_gc(FAM, GP)> gen;
 #pragma unroll
         for (int ks = 0; ks < VS; ++ks) {
             float av[8];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(KV_WS_THREADS, KV_WS_THREADS / 256) void kan_fwd_ws
         bf16x8_t phi[NK];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            BasisGen<FAM> gen;
+            BasisGen<FAM, kv_gc(FAM, GP)> gen;
 #pragma unroll
             for (int ks = 0; ks < VS; ++ks) {
                 float av[8];
@@ -445,8 +445,8 @@ FwdRegBf16Plan plan_fwd_reg_bf16(const kanvit_layer_desc* d) {
     p.gp = gp_of(d);
     const int fam = d->family;
     const bool gp_ok = (fam == KANVIT_LINEAR && p.gp == 1) || (fam == KANVIT_CHEBY && p.gp == 5) ||
-                       (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) ||
-                       (fam == KANVIT_RBF && p.gp == 9 && kv_rbf_reg_ok(d->flags, d->G)) || (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 28)) ||
+                       (fam == KANVIT_BSPLINE && p.gp == 9 && d->has_base && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3) ||
+                       (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) || (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 28)) ||
                        (fam == KANVIT_FOURIER && p.gp == 56);
     if (!gp_ok) return p;
     p.nt = d->O <= 32 ? 1 : (d->O <= 64 ? 2 : 4);
