@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, FAM == KV_SINE ? 1 : 2) void kan_bwd_input_reg
 #pragma unroll
         for (int q = 0; q < WQ; ++q) {
             const int v = tid + q * 256;
-            if (v < NV) wreg[q] = *reinterpret_cast<const u32x4*>(src + (long long)v * 8);
+            wreg[q] = *reinterpret_cast<const u32x4*>(src + (long long)(v < NV ? v : 0) * 8);      // unconditional (predicated loads serialise: a branch + vmcnt wait each); lanes past NV re-read vector 0, never stored
         }
     };
     auto store_w = [&](int buf) {

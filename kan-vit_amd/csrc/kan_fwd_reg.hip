@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
     const int n0 = (blockIdx.x - gs * ntn) * BN;
     const int nsets = a.groups / NSH;
     const long long m0 = (long long)blockIdx.y * BM;
-    const int GP = a.GP, KC = IC * GP;            // k rows per chunk (even)
+    const int GP = GPC > 0 ? GPC : a.GP, KC = IC * GP;      // k rows per chunk (even); compile-time in the GPC instantiations (host: a.GP == GPC)
     const int nch = a.I / IC;
     const int WSZ = KC * WROW;
     const int mrem = (m0 + BM <= a.M) ? BM : (int)(a.M - m0);
@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
             const int g = (NSH == 1) ? gs : p * nsets + gs;
             const float* src = a.w + ((long long)g * a.K + (long long)c * KC) * a.O + n0 + wc;      // chunk base (natural k order)
 #pragma unroll
-            for (int q = 0; q < WQ; ++q)
-                if (koff[q] >= 0) wreg[p][q] = *reinterpret_cast<const f32x4*>(src + koff[q]);
+            for (int q = 0; q < WQ; ++q)      // unconditional: a predicated load is a branch around it plus an s_waitcnt vmcnt(1) in front of every
+                if (q * WRS < KC)             // load (two in flight instead of all of them); rows past KC re-read row 0 and are never stored
+                    wreg[p][q] = *reinterpret_cast<const f32x4*>(src + (koff[q] >= 0 ? koff[q] : 0));
         }
     };
     auto store_w = [&](int buf) {

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
             for (int q = 0; q < WQ; ++q) {
                 const int v = tid + q * 256;
                 const int kr = v / BN, n = v & (BN - 1);          // kr = ks*2 + h
-                if (v < NV) wreg[p][q] = *reinterpret_cast<const u32x4*>(src + ((long long)kr * a.O + n0 + n) * 8);
+                if (q * 256 < NV)             // unconditional inside a live pass (a predicated load is a branch + a vmcnt wait per load); lanes past NV re-read vector 0
+                    wreg[p][q] = *reinterpret_cast<const u32x4*>(src + (v < NV ? ((long long)kr * a.O + n0 + n) * 8 : (long long)n0 * 8));
             }
         }
     };
