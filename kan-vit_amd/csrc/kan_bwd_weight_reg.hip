@@ -228,6 +228,12 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         if (jc == 0) run(std::integral_constant<int, 0>{});
         else if (NJC == 2 || jc == 1) run(std::integral_constant<int, JC>{});
         else if constexpr (NJC == 3) run(std::integral_constant<int, 2 * JC>{});
+    } else if constexpr (FAM == KV_BSPLINE || FAM == KV_RBF) {
+        // one window holding all GP = 9 values (FastKAN, also its bf16 mode): the window start is the constant 0 -- with a runtime
+        // start every value is a runtime-indexed select out of the eight Gaussians plus a branch around its own copy of silu
+        // (43 VALU instructions per MFMA in the bf16 launch, profiles/r03_sq_pmc_fast_vits_bf16.md)
+        static_assert(GP == 9, "compile-time windows assume G = 8 + the silu column (host-checked)");
+        run(std::integral_constant<int, 0>{});
     } else {
         run(std::integral_constant<int, -1>{});
     }
