@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
     float dxacc[FPH];
     float xv[FPH];
 
+    float lnp[RBF ? 2 * FPH : 1];               // FastKAN: (gamma | beta) of the chunk's features, or u (see the loop)
+    float2 ln_st = {0.0f, 1.0f};                  // KANVIT_FLAG_FUSED_LN: (mean, rstd) of this lane's row and x slice -- the same for every step
+    if constexpr (RBF) {
+        if (a.ln) ln_st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
+    }
     int ci = 0, p = 0, cn = 0;
     load_w(0, gx, 0);
     load_dy(gx, 0);
@@ -125,6 +130,26 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
             } else {
 #pragma unroll
                 for (int j = 0; j < FPH; ++j) xv[j] = xrow[ci * IC + j];
+            }
+        }
+        // FastKAN: what the chain rule at the END of this (feature chunk, group) needs besides x -- gamma / beta or u -- is requested
+        // here, BEFORE the next step's W / dY prefetch.  Memory returns in order: requested inside the chain rule these loads sat
+        // behind the prefetch, and every chain rule began by waiting for it.
+        if constexpr (RBF) {
+            if (cn == 0) {
+                const int g = p * a.xmod + gx;
+                if (a.ln) {
+                    const float* gb = a.bp + (long long)g * a.bp_stride + a.G + ci * IC + hf * FPH;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) {
+                        lnp[j] = gb[j];
+                        lnp[FPH + j] = gb[a.I + j];
+                    }
+                } else {
+                    const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) lnp[j] = urow[j];
+                }
             }
         }
         // this step's dY values (register copy), then prefetch the next step's operands
@@ -168,14 +193,11 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
             float uvv[RBF ? FPH : 1];
             if constexpr (RBF) {
                 if (a.ln) {                       // KANVIT_FLAG_FUSED_LN: u from x, the saved row statistics and this group's gamma / beta
-                    const float2 st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
-                    const float* gb = b.bp + a.G + ci * IC + hf * FPH;
 #pragma unroll
-                    for (int j = 0; j < FPH; ++j) uvv[j] = (xv[j] - st.x) * st.y * gb[j] + gb[a.I + j];
+                    for (int j = 0; j < FPH; ++j) uvv[j] = (xv[j] - ln_st.x) * ln_st.y * lnp[j] + lnp[FPH + j];
                 } else {
-                    const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
 #pragma unroll
-                    for (int j = 0; j < FPH; ++j) uvv[j] = urow[j];
+                    for (int j = 0; j < FPH; ++j) uvv[j] = lnp[j];
                 }
             }
             float dfq[SINE ? GP : 1];

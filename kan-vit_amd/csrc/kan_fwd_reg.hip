@@ -159,21 +159,48 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
         }
     };
 
+    // SINE with a compile-time basis size: the phases p[i][g] of the chunk's features travel one chunk ahead like x.  Read inside
+    // the basis evaluation they are issued AFTER the next chunk's W / x prefetch, and memory returns in order: every chunk then
+    // began by waiting for its own prefetch (s_waitcnt vmcnt(3) behind eight 16-byte loads).
+    constexpr bool SINE_PH = (FAM == KV_SINE && GPC > 0);
+    constexpr int NPH = SINE_PH ? ICH * GPC : 1;
+    float phv[NPH];
+    auto load_ph = [&](int c) {
+        if constexpr (SINE_PH) {
+            const float* ps = b.bp + GPC + (long long)(c * IC + hf * ICH) * GPC;      // [ICH features][GPC phases], contiguous
+            if constexpr ((ICH * GPC) % 4 == 0) {
+#pragma unroll
+                for (int e4 = 0; e4 < NPH / 4; ++e4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ps + 4 * e4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) phv[4 * e4 + e] = v[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NPH; ++e) phv[e] = ps[e];
+            }
+        }
+    };
+
     load_w(0);
     load_x(0);
+    load_ph(0);
     store_w(0);
     __syncthreads();
 
     for (int c = 0; c < nch; ++c) {
-        float xc[ICH], uc[ICH];
+        float xc[ICH], uc[ICH], phc[NPH];
 #pragma unroll
         for (int e = 0; e < ICH; ++e) {
             xc[e] = xv[e];
             uc[e] = RBF ? uv[e] : 0.0f;
         }
+#pragma unroll
+        for (int e = 0; e < NPH; ++e) phc[e] = phv[e];
         if (c + 1 < nch) {                        // prefetch the next chunk; lands while this chunk's MFMAs run
             load_w(c + 1);
             load_x(c + 1);
+            load_ph(c + 1);
         }
         const float* wp = W_s + (c & 1) * WSZ + hf * WROW + l31;
         if constexpr (GPC > 0) {
@@ -185,7 +212,10 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
                 BasisGen<FAM, kv_gc(FAM, GPC)> gen;       // compile-time G: one silu per feature, no branch per value (host-checked has_base)
                 gen.init(b, xc[j], uc[j], c * IC + hf * ICH + j);
 #pragma unroll
-                for (int g = 0; g < GPC; ++g) phi[j * GPC + g] = gen.next(g);
+                for (int g = 0; g < GPC; ++g) {
+                    if constexpr (SINE_PH) phi[j * GPC + g] = kv_sin(__fadd_rn(__fmul_rn(xc[j], b.bp[g]), phc[j * GPC + g]));      // BasisGen<KV_SINE>::next with the phase from registers
+                    else phi[j * GPC + g] = gen.next(g);
+                }
             }
             float wa[2][NTT];
 #pragma unroll
@@ -298,6 +328,7 @@ int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
                         ((a.M + BM - 1) / BM) * a.xmod >= N_CU;
     const int nsh = share3 ? 3 : 1;
     if ((a.O & 3) || (a.ldy & 3) || ((uintptr_t)a.y & 15) || ((uintptr_t)a.w & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return 1;
+    if (FAM == KV_SINE && (((uintptr_t)a.bp & 15) || (a.bp_stride & 3))) return 1;      // the phase rows are prefetched as 16-byte vectors
     const int wrow = 32 * nt * nsh, wrs = 256 / (8 * nt);
     for (int ich = 4; ich >= 1; ich >>= 1) {
         const int ic = 2 * ich, kc = ic * a.GP;

@@ -139,21 +139,43 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
         }
     };
 
+    // SINE: the phases of the chunk's features travel one chunk ahead like x (read inside the basis evaluation they are requested
+    // after the next chunk's prefetch and, memory returning in order, wait for all of it -- see kan_fwd_reg_kernel)
+    constexpr bool SINE_PH = (FAM == KV_SINE);
+    constexpr int NPH = SINE_PH ? VH : 1;
+    float phv[NPH];
+    auto load_ph = [&](int c) {
+        if constexpr (SINE_PH) {
+            const float* ps = b.bp + GP + (long long)(c * IC + hf * ICH) * GP;      // [ICH features][GP phases], contiguous (host: 16-byte aligned)
+#pragma unroll
+            for (int e4 = 0; e4 < NPH / 4; ++e4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ps + 4 * e4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) phv[4 * e4 + e] = v[e];
+            }
+        }
+    };
+    static_assert(!SINE_PH || VH % 4 == 0, "phase rows are read as 16-byte vectors");
+
     load_w(0);
     load_x(0);
+    load_ph(0);
     store_w(0);
     __syncthreads();
 
     for (int c = 0; c < nch; ++c) {
-        float xc[ICH], uc[ICH];
+        float xc[ICH], uc[ICH], phc[NPH];
 #pragma unroll
         for (int e = 0; e < ICH; ++e) {
             xc[e] = xv[e];
             uc[e] = RBF ? uv[e] : 0.0f;
         }
+#pragma unroll
+        for (int e = 0; e < NPH; ++e) phc[e] = phv[e];
         if (c + 1 < nch) {
             load_w(c + 1);
             load_x(c + 1);
+            load_ph(c + 1);
         }
         const unsigned short* wp = W_s + (size_t)(c & 1) * WSZ + ((size_t)hf * WROW + l31) * 8;
         BasisGen<FAM, kv_gc(FAM, GP)> gen;
@@ -167,8 +189,12 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
                 const int vi = ks * 8 + e;                        // compile-time after unrolling
                 const int j = vi / GP, g = vi - j * GP;
                 if (vi < VH) {
-                    if (g == 0) gen.init(b, xc[j], uc[j], c * IC + hf * ICH + j);
-                    av[e] = gen.next(g);
+                    if constexpr (SINE_PH) {
+                        av[e] = kv_sin(__fadd_rn(__fmul_rn(xc[j], b.bp[g]), phc[vi]));      // BasisGen<KV_SINE>::next with the phase from registers
+                    } else {
+                        if (g == 0) gen.init(b, xc[j], uc[j], c * IC + hf * ICH + j);
+                        av[e] = gen.next(g);
+                    }
                 } else {
                     av[e] = 0.0f;
                 }
@@ -462,6 +488,7 @@ FwdRegBf16Plan plan_fwd_reg_bf16(const kanvit_layer_desc* d) {
     p.lds = (size_t)2 * p.vs * 2 * 32 * p.nt * p.nsh * 16;
     if (p.lds < sizeof(float) * 4 * 32 * 36) p.lds = sizeof(float) * 4 * 32 * 36;
     if (p.lds > 160 * 1024) return p;
+    if (fam == KANVIT_SINE && (d->bparam_stride & 3)) return p;      // phase rows are prefetched as 16-byte vectors (the pointer itself is checked at launch)
     if ((p.vs * 2 * 32 * p.nt + 255) / 256 > 12) return p;
     p.ws_bytes = (size_t)d->groups * p.nch * p.vs * 2 * d->O * 16;
     p.ok = true;

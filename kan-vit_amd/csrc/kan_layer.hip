@@ -202,7 +202,7 @@ int kanvit_layer_fwd(const kanvit_layer_desc* d, const float* x, const float* u,
     hipStream_t st = (hipStream_t)stream;
     if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16) {
         const FwdRegBf16Plan pr = plan_fwd_reg_bf16(d);
-        if (pr.ok && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)(u ? u : x) | (uintptr_t)(bias ? bias : x)) & 15)) {
+        if (pr.ok && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)(u ? u : x) | (uintptr_t)(bias ? bias : x) | (uintptr_t)(bparams ? bparams : x)) & 15)) {
             if (!workspace || workspace_bytes < pr.ws_bytes || ((uintptr_t)workspace & 15))
                 return kv_fail(KANVIT_ENOMEM, "kanvit_layer_fwd: workspace %zu bytes < required %zu (or not 16-byte aligned)",
                                workspace_bytes, pr.ws_bytes);
