@@ -345,48 +345,47 @@ __global__ __launch_bounds__(BF ? 256 : 512, 2) void attn_fwd2_kernel(const Attn
         constexpr int C4 = D / 4;                       // float4 per row
         const int c4 = (tid % C4) * 4, r0 = tid / C4;
         constexpr int RP = NTHR / C4;                   // rows per pass
+        // ALL of the head's K and V rows are requested before anything is converted: 2 * NKT * 32 / RP float4 per thread in flight
+        // (28 for N = 197) -- one memory round trip for the fill instead of one per 64 rows (seven of them, each exposed: the
+        // work-group has nothing else to do until the barrier below)
+        constexpr int KQ = (NKT * 32 + RP - 1) / RP;    // K rows per thread
+        constexpr int VQ = (NKT * 16 + RP - 1) / RP;    // V row PAIRS per thread
+        f32x4 kx[KQ], v0[VQ], v1[VQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int key = q * RP + r0;
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (key < N) t = *reinterpret_cast<const f32x4*>(kb + (long long)key * a.ksn + c4);
+            kx[q] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+            const int key = 2 * (q * RP + r0);
+            f32x4 t0 = {0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;
+            if (key < N) t0 = *reinterpret_cast<const f32x4*>(vb + (long long)key * a.vsn + c4);
+            if (key + 1 < N) t1 = *reinterpret_cast<const f32x4*>(vb + (long long)(key + 1) * a.vsn + c4);
+            v0[q] = t0;
+            v1[q] = t1;
+        }
         // K: [key][d] rows, 4 floats -> 4 bf16 (8 bytes)
-        for (int rb = 0; rb < NP; rb += 4 * RP) {
-            f32x4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int key = rb + q * RP + r0;
-                f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (key < N) t = *reinterpret_cast<const f32x4*>(kb + (long long)key * a.ksn + c4);
-                v[q] = t;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int key = rb + q * RP + r0;
-                if (key < NP) {
-                    unsigned* dst = reinterpret_cast<unsigned*>(Kb + key * KB + c4);
-                    dst[0] = kv_pk(v[q][0], v[q][1]);
-                    dst[1] = kv_pk(v[q][2], v[q][3]);
-                }
+        for (int q = 0; q < KQ; ++q) {
+            const int key = q * RP + r0;
+            if (key < NP) {
+                unsigned* dst = reinterpret_cast<unsigned*>(Kb + key * KB + c4);
+                dst[0] = kv_pk(kx[q][0], kx[q][1]);
+                dst[1] = kv_pk(kx[q][2], kx[q][3]);
             }
         }
         // V: key pairs (2m, 2m+1) are adjacent slots of the transposed image
-        const int NPAIR = NP / 2;
-        for (int pb = 0; pb < NPAIR; pb += 2 * RP) {
-            f32x4 v0[2], v1[2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int key = 2 * (pb + q * RP + r0);
-                f32x4 t0 = {0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0;
-                if (key < N) t0 = *reinterpret_cast<const f32x4*>(vb + (long long)key * a.vsn + c4);
-                if (key + 1 < N) t1 = *reinterpret_cast<const f32x4*>(vb + (long long)(key + 1) * a.vsn + c4);
-                v0[q] = t0;
-                v1[q] = t1;
-            }
+        for (int q = 0; q < VQ; ++q) {
+            const int key = 2 * (q * RP + r0);
+            if (key < NP) {
+                const int pos = (key & ~31) + kv_key_slot(key & 31);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int key = 2 * (pb + q * RP + r0);
-                if (key < NP) {
-                    const int pos = (key & ~31) + kv_key_slot(key & 31);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        *reinterpret_cast<unsigned*>(Vt + (c4 + e) * VB + pos) = kv_pk(v0[q][e], v1[q][e]);
-                }
+                for (int e = 0; e < 4; ++e)
+                    *reinterpret_cast<unsigned*>(Vt + (c4 + e) * VB + pos) = kv_pk(v0[q][e], v1[q][e]);
             }
         }
     }
@@ -988,7 +987,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs a) {
         const long long bi = bh / a.H;
         const float* op = a.o + bi * a.osb + hi * a.osh + (long long)n * a.osn;
         const float* dp = a.d_o + bi * a.osb + hi * a.osh + (long long)n * a.osn;
-        for (int c = sub; c < a.D; c += 16) s += op[c] * dp[c];
+        if (a.vec && (a.D & 3) == 0 && (((uintptr_t)op | (uintptr_t)dp) & 15) == 0) {      // 16 lanes x 16 bytes = one 64-float row per trip
+            for (int c = sub * 4; c < a.D; c += 64) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(op + c), y = *reinterpret_cast<const f32x4*>(dp + c);
+                s += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+            }
+        } else {
+            for (int c = sub; c < a.D; c += 16) s += op[c] * dp[c];
+        }
     }
     s += __shfl_xor(s, 8);
     s += __shfl_xor(s, 4);
@@ -1275,7 +1281,7 @@ __global__ __launch_bounds__(ATHR) void attn_bwd_q_kernel(const AttnArgs a) {
 //   * 8 waves, one tile each: one barrier per kernel (after the LDS fill).
 // =============================================================================================
 // Fill bf16 images of src[n][D] (fp32, row stride `stride`): rowimg[n][D + 8] and/or timg[d][NP + 8]; rows >= N are zero.
-template <int DT, int NTHR>
+template <int DT, int NTHR, bool NATURAL = false>      // NATURAL: the transposed image keeps the rows of a tile in natural order (operand read from memory, not from accumulators)
 __device__ __forceinline__ void fill_bf16_images(unsigned short* __restrict__ rowimg, unsigned short* __restrict__ timg,
                                                  const float* __restrict__ src, long long stride, int NP, int N, int tid) {
     constexpr int D = 32 * DT, C4 = D / 4, RP = NTHR / C4, KB = D + 8;
@@ -1306,7 +1312,7 @@ __device__ __forceinline__ void fill_bf16_images(unsigned short* __restrict__ ro
                     d1[1] = kv_pk(v1[q][2], v1[q][3]);
                 }
                 if (timg) {
-                    const int pos = (n & ~31) + kv_key_slot(n & 31);
+                    const int pos = NATURAL ? n : (n & ~31) + kv_key_slot(n & 31);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(timg + (c4 + e) * VB + pos) = kv_pk(v0[q][e], v1[q][e]);
                 }
@@ -1443,9 +1449,15 @@ __global__ __launch_bounds__(512) void attn_bwd_kv2_kernel(const AttnArgs a) {
                 pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
             }
             if constexpr (DSOUT) {       // dS[q][key] for the dQ kernel: row = q (register), 32 consecutive keys per lane half
-                float* dsp = a.ds + ((long long)bh * NP + qt * 32) * NP + jt * 32 + l31;
+                if constexpr (BF) {      // bf16 mode: the hand-off is the bf16 operand the dQ product consumes (attn_bwd_dq_bf16_kernel)
+                    unsigned short* dsp = reinterpret_cast<unsigned short*>(a.ds) + ((long long)bh * NP + qt * 32) * NP + jt * 32 + l31;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dsp[(long long)kv_acc_row(r, hf) * NP] = pacc[r];
+                    for (int r = 0; r < 16; ++r) dsp[(long long)kv_acc_row(r, hf) * NP] = (unsigned short)(kv_pk(pacc[r], 0.0f) & 0xffffu);
+                } else {
+                    float* dsp = a.ds + ((long long)bh * NP + qt * 32) * NP + jt * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dsp[(long long)kv_acc_row(r, hf) * NP] = pacc[r];
+                }
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
             if constexpr (BF) {
@@ -1582,6 +1594,55 @@ __global__ __launch_bounds__(512) void attn_bwd_q2_kernel(const AttnArgs a) {
         }
         if (q_ok) store_acc_rows<DT>(dqb + (long long)qrow * a.qsn, dqacc, hf, 1.0f);
     }
+}
+
+// dQ from the stored dS, bf16 mode: dQ^T[d][q] = sum_key K^T[d][key] dS[q][key] with dS already bf16 in memory (written by
+// attn_bwd_kv2_kernel<DT, true, true>) -- one product and no exponentials instead of attn_bwd_q2_kernel's three products, two
+// row images and 16*nkt exp2 per lane.  K^T is a bf16 image [d][NP + 8] in natural key order (A operand: one ds_read_b128 per
+// k-step); the B operand is 8 consecutive keys of the lane's OWN dS row, one 16-byte global load per k-step, all 2*nkt of them
+// requested before the first product.  8 waves, one query tile each, one barrier (after the fill).
+template <int DT, int NKT>
+__global__ __launch_bounds__(512) void attn_bwd_dq_bf16_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * DT, NTHR = 512, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int N = a.N, nkt = a.nkt, NP = nkt * 32, VB = NP + 8;
+    unsigned short* Kt = reinterpret_cast<unsigned short*>(smem);      // [D][VB]
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
+    const unsigned short* dsb = reinterpret_cast<const unsigned short*>(a.ds) + (long long)bh * NP * NP;
+
+    // this wave's dS fragments first (they do not depend on the fill): rows >= N of a tile were written as zeros by the kv kernel
+    const int qt = wave;
+    const int qrow = qt * 32 + l31;
+    bf16x8_t dsf[2 * NKT];
+    if (qt < nkt) {
+        const unsigned short* dsr = dsb + (long long)qrow * NP + 8 * hf;
+#pragma unroll
+        for (int f = 0; f < 2 * NKT; ++f)
+            if (f < 2 * nkt) dsf[f] = *reinterpret_cast<const bf16x8_t*>(dsr + 16 * f);
+    }
+    fill_bf16_images<DT, NTHR, true>(nullptr, Kt, kb, a.ksn, NP, N, tid);
+    __syncthreads();
+    if (qt >= nkt) return;
+
+    f32x16 dqacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+    const unsigned short* kr = Kt + l31 * VB + 8 * hf;
+#pragma unroll
+    for (int f = 0; f < 2 * NKT; ++f) {
+        if (f < 2 * nkt) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(kr + dt * 32 * VB + 16 * f), dsf[f],
+                                                                    dqacc[dt], 0, 0, 0);
+        }
+    }
+    if (qrow < N) store_acc_rows<DT>(dqb + (long long)qrow * a.qsn, dqacc, hf, 1.0f);
 }
 
 // dQ from the stored dS (fp32 path): dQ^T[d][q] = sum_key K^T[d][key] dS[q][key] -- one product instead of the three of
@@ -2282,6 +2343,17 @@ int launch_bwd2(const AttnArgs& a, hipStream_t st) {
             return 0;
         }
     }
+    if constexpr (BF) {
+        if (a.ds && a.nkt <= 8) {      // bf16 dS hand-off: the key-stationary kernel stores dS as bf16, dQ is one product (no recomputation)
+            KV_ALLOW_LDS(160 * 1024, (attn_bwd_kv2_kernel<DT, true, true>));
+            hipLaunchKernelGGL((attn_bwd_kv2_kernel<DT, true, true>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_kv, st, a);
+            KV_LAUNCH_CHECK("attn_bwd_kv2_kernel");
+            if (a.nkt <= 4) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DT, 4>), dim3((unsigned)(a.B * a.H)), dim3(512), tr, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DT, 8>), dim3((unsigned)(a.B * a.H)), dim3(512), tr, st, a);
+            KV_LAUNCH_CHECK("attn_bwd_dq_bf16_kernel");
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((attn_bwd_kv2_kernel<DT, BF, false>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_kv, st, a);
     KV_LAUNCH_CHECK("attn_bwd_kv2_kernel");
     hipLaunchKernelGGL((attn_bwd_q2_kernel<DT, BF>), dim3((unsigned)(a.B * a.H)), dim3(512), lds_q, st, a);
@@ -2496,16 +2568,19 @@ int kanvit_attn_fwd(const kanvit_attn_desc* d, const float* q, const float* k, c
 
 // rowsum(dO*O) [B*H*N] (rounded up to 16 bytes), then -- exact fp32 path with D in {32, 64} only -- dS [B*H][NP][NP]
 static size_t attn_delta_bytes(const kanvit_attn_desc* d) { return (sizeof(float) * (size_t)d->B * d->H * d->N + 15) / 16 * 16; }
+static bool attn_bf16_mode(const kanvit_attn_desc* d) { return (d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !kv_config().no_bf16; }
+// dS hand-off from the key-stationary kernel to the dQ kernel: fp32 values on the exact path, bf16 values in bf16 mode (there the
+// dQ product consumes them as a bf16 operand anyway; needs one query tile per wave of the 512-thread kernels: N <= 256)
 static bool attn_ds_spill(const kanvit_attn_desc* d) {
-    return !(d->flags & KANVIT_FLAG_BF16_MFMA) && (d->D == 32 || d->D == 64) && !d->causal && !kv_config().attn_no_ds &&
-           !kv_config().attn_v1;
+    if (!(d->D == 32 || d->D == 64) || d->causal || kv_config().attn_no_ds || kv_config().attn_v1) return false;
+    return attn_bf16_mode(d) ? d->N <= 256 : true;
 }
 size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d) {
     if (!d || d->B < 0 || d->H < 1 || d->N < 1) return 0;
     size_t n = attn_delta_bytes(d);
     if (attn_ds_spill(d)) {
         const size_t np = (size_t)(d->N + 31) / 32 * 32;
-        n += sizeof(float) * (size_t)d->B * d->H * np * np;
+        n += (attn_bf16_mode(d) ? sizeof(unsigned short) : sizeof(float)) * (size_t)d->B * d->H * np * np;
     }
     return n;
 }
@@ -2536,15 +2611,14 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
     const long long rows = (long long)d->B * d->H * d->N;
     // the third-form fp32 kernels form rowsum(dO*O) themselves; every other path reads it from the workspace
     const size_t lds3 = sizeof(float) * ((size_t)2 * a.nkt * 32 * kv_pad4(d->D) + 2 * (size_t)a.nkt * 32);
-    const bool third = a.ds && !kv_config().attn_v2 && !kv_config().attn_v1 && a.vec && (d->D == 32 || d->D == 64) &&
+    const bool third = a.ds && !attn_bf16_mode(d) && !kv_config().attn_v2 && !kv_config().attn_v1 && a.vec && (d->D == 32 || d->D == 64) &&
                        (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)o) % 16 == 0) && lds3 <= 160 * 1024;
     a.third = third ? 1 : 0;
     if (!third) {
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
         KV_LAUNCH_CHECK("attn_delta_kernel");
     }
-    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && d->D % 16 == 0 && !kv_config().no_bf16)
-        return d->D <= 32 ? launch_bwd<1, true>(a, st) : launch_bwd<2, true>(a, st);
+    if (attn_bf16_mode(d)) return d->D <= 32 ? launch_bwd<1, true>(a, st) : launch_bwd<2, true>(a, st);
     return d->D <= 32 ? launch_bwd<1, false>(a, st) : launch_bwd<2, false>(a, st);
 }
 

@@ -109,6 +109,44 @@ def test_bf16_mfma_attention_close_to_fp32(n, d):
             assert 0 < err < 3e-2, err
 
 
+@pytest.mark.parametrize("n,d", [(50, 32), (65, 64), (197, 64), (224, 64), (256, 32)])
+def test_bf16_ds_handoff_equals_recomputation(n, d, monkeypatch):
+    """bf16 mode, backward: the key-stationary kernel hands dS to the dQ kernel as bf16 (one product, attn_bwd_dq_bf16_kernel)
+    instead of the dQ kernel recomputing S, dP and the exponentials (KANVIT_ATTN_NO_DS=1: attn_bwd_q2_kernel).  dK / dV come from
+    the same kernel either way -> bitwise equal; dQ is the same product of the same bf16-rounded factors up to where the rounding
+    of dS happens -> both within the bf16 bound of the exact fp32 gradient, and close to each other."""
+    from kanvit import _lib, ops
+    torch.manual_seed(n + d)
+    q, k, v = (torch.randn(3, 4, n, d, device=DEV, requires_grad=True) for _ in range(3))
+    do = torch.randn(3, 4, n, d, device=DEV)
+
+    def run(amp):
+        for t in (q, k, v):
+            t.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            o = ops.attention(q, k, v)
+        o.backward(do)
+        return q.grad.clone(), k.grad.clone(), v.grad.clone()
+
+    exact = run(False)
+    monkeypatch.delenv("KANVIT_ATTN_NO_DS", raising=False)
+    _lib.reload_config()
+    handoff = run(True)
+    monkeypatch.setenv("KANVIT_ATTN_NO_DS", "1")
+    _lib.reload_config()
+    recomputed = run(True)
+    monkeypatch.delenv("KANVIT_ATTN_NO_DS", raising=False)
+    _lib.reload_config()
+    assert torch.equal(handoff[1], recomputed[1]) and torch.equal(handoff[2], recomputed[2])
+    scale = float(exact[0].abs().max())
+    e_new = float((handoff[0] - exact[0]).abs().max()) / scale
+    e_old = float((recomputed[0] - exact[0]).abs().max()) / scale
+    assert 0 < e_new < 3e-2 and e_new < 1.5 * e_old + 1e-3, (e_new, e_old)
+    assert float((handoff[0] - recomputed[0]).abs().max()) / scale < 2e-2
+    again = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(handoff, again))      # deterministic
+
+
 @pytest.mark.parametrize("b,h,n,d,causal", [(128, 8, 17, 8, False), (3, 5, 32, 32, True), (2, 2, 1, 2, False), (7, 3, 31, 18, True),
                                                  (128, 2, 50, 32, False), (3, 3, 33, 32, True), (5, 1, 64, 16, False), (2, 7, 47, 8, True)])
 def test_small_head_kernels_packed_layout_and_determinism(b, h, n, d, causal):
