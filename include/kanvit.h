@@ -262,6 +262,10 @@ int kanvit_addln_bwd(int64_t M, int D, const float* xsum, const float* gamma, co
 size_t kanvit_relu_bwd_bias_workspace(int64_t M, int N);
 int kanvit_relu_bwd_bias(int64_t M, int N, const float* dy, const float* y, float* dh, float* dbias, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The same on bf16 tensors (torch.autocast): dy, y, dh are bf16 [M][N] (16-byte aligned, N % 4 == 0); dbias and the workspace stay
+ * fp32 (sizes as above).  (ABI >= 6) */
+int kanvit_relu_bwd_bias_bf16(int64_t M, int N, const void* dy_bf16, const void* y_bf16, void* dh_bf16, float* dbias, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---- three-term bf16 split image (opt-in "bf16x3" feed-forward mode, kanvit/dense.py) --------------------------------
  * v = hi + lo, hi = bf16(v), lo = bf16(v - hi).  Writes out[M][3K] (bf16) = [hi|hi|lo] (pattern 0) or [hi|lo|hi]

@@ -1,6 +1,6 @@
 // Backward epilogue of the feed-forward's first Linear + ReLU (reference model.py:25-29): the ReLU mask
 // of the incoming gradient and the bias gradient in ONE pass over [M, N].
-//     dh[m][n]  = y[m][n] > 0 ? dy[m][n] : 0          (what autograd's threshold_backward does for ReLU(inplace) on the saved y)
+//     dh[m][n]  = y[m][n] <= 0 ? 0 : dy[m][n]         (what autograd's threshold_backward does for ReLU(inplace) on the saved y)
 //     dbias[n]  = sum_m dh[m][n]
 // Stock torch runs two passes (threshold_backward: read dy, y, write dh; then sum(0): read dh again -- 12 x 310 MB per ViT-B
 // step for the second one).  Here a work-group owns a band of rows x 1024 columns: each thread streams one float4 column group
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(EP_THREADS) void relu_bwd_bias_kernel(const float* 
 #pragma unroll
         for (int q = 0; q < EP_ROWS; ++q) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[q][e] = a[q][e] > 0.0f ? g[q][e] : 0.0f;
+            for (int e = 0; e < 4; ++e) g[q][e] = a[q][e] <= 0.0f ? 0.0f : g[q][e];      // threshold_backward's own comparison (a NaN activation passes the gradient)
             EP_ST(g[q], reinterpret_cast<f32x4*>(dh + (r + q) * N + c));
             s += g[q];                         // rows added in order
         }
@@ -57,9 +57,58 @@ __global__ __launch_bounds__(EP_THREADS) void relu_bwd_bias_kernel(const float* 
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * N + c);
         const f32x4 a = *reinterpret_cast<const f32x4*>(y + r * N + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.0f ? g[e] : 0.0f;
+        for (int e = 0; e < 4; ++e) g[e] = a[e] <= 0.0f ? 0.0f : g[e];
         *reinterpret_cast<f32x4*>(dh + r * N + c) = g;
         s += g;
+    }
+    *reinterpret_cast<f32x4*>(part + (long long)blockIdx.y * N + c) = s;
+}
+
+// The same pass on bf16 tensors (torch.autocast: dy, y and dh are bf16; the column sums stay fp32, as torch's
+// `dy.sum(0, dtype=float32)`): 8-byte loads of four bf16 per thread, the same 1024 columns per work-group and band partials.
+typedef unsigned short ep_u16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(EP_THREADS) void relu_bwd_bias_bf16_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+                                                                        unsigned short* __restrict__ dh, float* __restrict__ part, long long M,
+                                                                        int N, long long rows_per_band) {
+    const int c = (blockIdx.x * EP_THREADS + threadIdx.x) * 4;
+    if (c >= N) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_band;
+    long long r1 = r0 + rows_per_band;
+    if (r1 > M) r1 = M;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int RB = 2 * EP_ROWS;                         // rows in flight (half the bytes per row)
+    long long r = r0;
+    for (; r + RB <= r1; r += RB) {
+        ep_u16x4 g[RB], a[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            g[q] = EP_LD(reinterpret_cast<const ep_u16x4*>(dy + (r + q) * N + c));
+            a[q] = EP_LD(reinterpret_cast<const ep_u16x4*>(y + (r + q) * N + c));
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // !(y <= 0) on the bf16 bit pattern (threshold_backward's comparison): positive and not zero, or a NaN of either sign
+                const unsigned short yb = a[q][e];
+                const bool pos = ((yb & 0x8000u) == 0 && yb != 0) || ((yb & 0x7f80u) == 0x7f80u && (yb & 0x007fu));
+                g[q][e] = pos ? g[q][e] : (unsigned short)0;
+                s[e] += __builtin_bit_cast(float, (unsigned)g[q][e] << 16);      // rows added in order
+            }
+            EP_ST(g[q], reinterpret_cast<ep_u16x4*>(dh + (r + q) * N + c));
+        }
+    }
+    for (; r < r1; ++r) {
+        ep_u16x4 g = *reinterpret_cast<const ep_u16x4*>(dy + r * N + c);
+        const ep_u16x4 a = *reinterpret_cast<const ep_u16x4*>(y + r * N + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned short yb = a[e];
+            const bool pos = ((yb & 0x8000u) == 0 && yb != 0) || ((yb & 0x7f80u) == 0x7f80u && (yb & 0x007fu));
+            g[e] = pos ? g[e] : (unsigned short)0;
+            s[e] += __builtin_bit_cast(float, (unsigned)g[e] << 16);
+        }
+        *reinterpret_cast<ep_u16x4*>(dh + r * N + c) = g;
     }
     *reinterpret_cast<f32x4*>(part + (long long)blockIdx.y * N + c) = s;
 }
@@ -112,8 +161,8 @@ size_t kanvit_relu_bwd_bias_workspace(int64_t M, int N) {
     return sizeof(float) * (size_t)ep_bands(M, N) * (size_t)N;
 }
 
-int kanvit_relu_bwd_bias(int64_t M, int N, const float* dy, const float* y, float* dh, float* dbias, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+static int relu_bwd_bias_impl(bool bf16, int64_t M, int N, const void* dy, const void* y, void* dh, float* dbias, void* workspace,
+                              size_t workspace_bytes, void* stream) {
     if (M < 0 || N < 1 || (N & 3)) return kv_fail(KANVIT_EINVAL, "kanvit_relu_bwd_bias: N=%d must be a positive multiple of 4 (M=%lld)", N, (long long)M);
     if (!dbias) return kv_fail(KANVIT_EINVAL, "kanvit_relu_bwd_bias: null dbias");
     hipStream_t st = (hipStream_t)stream;
@@ -129,11 +178,26 @@ int kanvit_relu_bwd_bias(int64_t M, int N, const float* dy, const float* y, floa
     const int bands = ep_bands(M, N);
     const long long rpb = (M + bands - 1) / bands;
     dim3 grid((unsigned)((N + EP_COLS - 1) / EP_COLS), (unsigned)((M + rpb - 1) / rpb), 1);
-    hipLaunchKernelGGL(relu_bwd_bias_kernel, grid, dim3(EP_THREADS), 0, st, dy, y, dh, (float*)workspace, (long long)M, N, rpb);
+    if (bf16)
+        hipLaunchKernelGGL(relu_bwd_bias_bf16_kernel, grid, dim3(EP_THREADS), 0, st, (const unsigned short*)dy, (const unsigned short*)y,
+                           (unsigned short*)dh, (float*)workspace, (long long)M, N, rpb);
+    else
+        hipLaunchKernelGGL(relu_bwd_bias_kernel, grid, dim3(EP_THREADS), 0, st, (const float*)dy, (const float*)y, (float*)dh, (float*)workspace,
+                           (long long)M, N, rpb);
     KV_LAUNCH_CHECK("relu_bwd_bias_kernel");
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, (const float*)workspace, dbias, N, (int)grid.y);
     KV_LAUNCH_CHECK("colsum_reduce_kernel");
     return 0;
+}
+
+int kanvit_relu_bwd_bias(int64_t M, int N, const float* dy, const float* y, float* dh, float* dbias, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    return relu_bwd_bias_impl(false, M, N, dy, y, dh, dbias, workspace, workspace_bytes, stream);
+}
+
+int kanvit_relu_bwd_bias_bf16(int64_t M, int N, const void* dy, const void* y, void* dh, float* dbias, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    return relu_bwd_bias_impl(true, M, N, dy, y, dh, dbias, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -89,6 +89,7 @@ SYMBOLS = {
     "kanvit_addln_bwd": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_relu_bwd_bias_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
     "kanvit_relu_bwd_bias": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kanvit_relu_bwd_bias_bf16": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_split3_bf16": (C.c_int, [C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int64, _P, C.c_int, _P]),
 }
 for _f in FAMILY_NAMES:

@@ -68,7 +68,7 @@ class _DenseFn(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             dy = dy.contiguous().to(xc.dtype)
             if ctx.relu:
-                if (dy.is_cuda and dy.dtype == torch.float32 and y.dtype == torch.float32 and y.is_contiguous() and dy.shape[1] % 4 == 0
+                if (dy.is_cuda and dy.dtype == y.dtype and dy.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous() and dy.shape[1] % 4 == 0
                         and ctx.has_bias and ctx.needs_input_grad[2] and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
                         and not _lib.py_switches()["no_ff_epi"]):
                     dy, db = _relu_bwd_bias(dy, y)      # ReLU mask + bias gradient in one pass (csrc/ff_epilogue.hip)
@@ -102,11 +102,12 @@ def _relu_bwd_bias(dy: torch.Tensor, y: torch.Tensor):
     L = _lib.lib()
     db = torch.empty(N, device=dy.device, dtype=torch.float32)
     out = torch.empty_like(dy)
+    fn = L.kanvit_relu_bwd_bias_bf16 if dy.dtype == torch.bfloat16 else L.kanvit_relu_bwd_bias      # autocast: bf16 tensors, fp32 column sums
     with torch.cuda.device(dy.device):
         nbytes = int(L.kanvit_relu_bwd_bias_workspace(M, N))
         ws = ops._workspace(nbytes, dy.device)
-        _lib.check(L.kanvit_relu_bwd_bias(M, N, ops._ptr(dy), ops._ptr(y), ops._ptr(out), ops._ptr(db), ops._ptr(ws), C.c_size_t(nbytes),
-                                          ops._stream()), "kanvit_relu_bwd_bias")
+        _lib.check(fn(M, N, ops._ptr(dy), ops._ptr(y), ops._ptr(out), ops._ptr(db), ops._ptr(ws), C.c_size_t(nbytes), ops._stream()),
+                   "kanvit_relu_bwd_bias")
     return out, db
 
 

@@ -109,8 +109,11 @@ def test_descriptor_layout_and_errors(lib):
     # rowsum(dO*O) per row (16-byte rounded) + the dS spill of the exact fp32 path: [B*H][NP][NP], NP = 224
     delta = (2 * 3 * 197 * 4 + 15) // 16 * 16
     assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta + 2 * 3 * 224 * 224 * 4
-    a.flags = 1                                   # bf16 matrix-core mode keeps the recompute kernels: no spill
-    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta
+    a.flags = 1                                   # bf16 matrix-core mode hands dS over as bf16 (round 3): half the spill
+    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta + 2 * 3 * 224 * 224 * 2
+    a.N = 300                                     # ... for N <= 256 (one query tile per wave of the dQ kernel); beyond, the recompute kernels
+    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == (2 * 3 * 300 * 4 + 15) // 16 * 16
+    a.N = 197
     a.flags = 0
 
 

@@ -38,6 +38,34 @@ def test_mask_and_column_sums(m, n):
     assert torch.equal(db, db2) and torch.equal(out, out2)     # ordered partial sums: bitwise run to run
 
 
+@pytest.mark.parametrize("m,n", [(3, 8), (100, 1028), (1333, 3072), (25216, 3072)])
+def test_bf16_mask_and_column_sums(m, n):
+    """The autocast variant: bf16 dy / y / dh, fp32 column sums (what `threshold_backward` + `sum(0, dtype=float32)` give)."""
+    from kanvit import _lib, ops
+    L = _lib.lib()
+    torch.manual_seed(m * 7 + n)
+    dy = torch.randn(m, n, device=DEV).bfloat16()
+    y = torch.relu(torch.randn(m, n, device=DEV)).bfloat16()
+    y[0, :4] = torch.tensor([float("nan"), -0.0, 0.0, float("-inf")], device=DEV).bfloat16()
+    out = torch.empty_like(dy)
+    db = torch.empty(n, device=DEV)
+    nb = int(L.kanvit_relu_bwd_bias_workspace(m, n))
+    ws = ops._workspace(nb, dy.device)
+    _lib.check(L.kanvit_relu_bwd_bias_bf16(m, n, ops._ptr(dy), ops._ptr(y), ops._ptr(out), ops._ptr(db), ops._ptr(ws), C.c_size_t(nb),
+                                           ops._stream()), "kanvit_relu_bwd_bias_bf16")
+    ref = torch.ops.aten.threshold_backward(dy, y, 0)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))          # bit patterns (the NaN-activation column passes dy through)
+    want = ref.double().sum(0)
+    assert float((db.double() - want).abs().max()) <= 2e-6 * max(1.0, float(ref.double().abs().sum(0).max()))
+
+
+def test_fp32_nan_activation_passes_the_gradient_like_torch():
+    y = torch.tensor([[float("nan"), -1.0, 0.0, 2.0]], device=DEV)
+    dy = torch.ones(1, 4, device=DEV)
+    out, _ = _call(dy, y)
+    assert torch.equal(out, torch.ops.aten.threshold_backward(dy, y, 0))
+
+
 def test_empty_and_bad_shapes():
     from kanvit import _lib
     L = _lib.lib()
