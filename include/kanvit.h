@@ -252,6 +252,15 @@ size_t kanvit_addln_bwd_workspace(int64_t M, int D);
 int kanvit_addln_bwd(int64_t M, int D, const float* xsum, const float* gamma, const float* mean, const float* rstd,
                      const float* dy, const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same two passes with bf16 tensors at the boundary (torch.autocast: the feed-forward's output `delta`, its input `y` and the
+ * gradient `dy` arriving from it are bf16; the residual stream x / xsum / dres / dx stays fp32): *_bf16 != 0 says that the pointer
+ * in front of it is bf16 [M][D]; dx_bf16, if not NULL, receives a second copy of dx rounded to bf16 (the gradient of a bf16
+ * delta).  With all flags 0 and dx_bf16 NULL these ARE kanvit_addln_fwd / _bwd.  (ABI >= 6) */
+int kanvit_addln_fwd_ex(int64_t M, int D, float eps, const float* x, const void* delta, int delta_bf16, const float* gamma, const float* beta,
+                        float* xsum, void* y, int y_bf16, float* mean, float* rstd, void* stream);
+int kanvit_addln_bwd_ex(int64_t M, int D, const float* xsum, const float* gamma, const float* mean, const float* rstd,
+                        const void* dy, int dy_bf16, const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- ReLU backward + bias gradient of the feed-forward's first Linear in one pass ----------------
  * The TransformerBlock's nn.Sequential(Linear, ReLU(inplace), Linear) (model.py:25-29): what autograd runs for the ReLU and

@@ -39,12 +39,31 @@ struct LnArgs {
     const float* dres;
     float* dx;
     float* part;      // [work-groups][2][D]
+    unsigned short* dx_bf16;      // optional second copy of dx, rounded to bf16 (the gradient of a bf16 `delta`)
     long long M;
     int D;
     float eps;
 };
 
-template <int NV>
+// bf16 tensors at the boundary (torch.autocast: the feed-forward's output / input / input gradient are bf16): 4 values = 8 bytes
+typedef unsigned short ln_u16x4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ f32x4 ln_ld4(const float* base, long long idx) {      // idx in elements; `base` is a bf16 pointer when BF
+    if constexpr (BF) {
+        const ln_u16x4 u = *reinterpret_cast<const ln_u16x4*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        return f32x4{__builtin_bit_cast(float, (unsigned)u[0] << 16), __builtin_bit_cast(float, (unsigned)u[1] << 16),
+                     __builtin_bit_cast(float, (unsigned)u[2] << 16), __builtin_bit_cast(float, (unsigned)u[3] << 16)};
+    } else {
+        return *reinterpret_cast<const f32x4*>(base + idx);
+    }
+}
+__device__ __forceinline__ ln_u16x4 ln_to_bf16(const f32x4& v) {               // round to nearest even, as torch's .to(bfloat16)
+    typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+    const ln_bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    return __builtin_bit_cast(ln_u16x4, b);
+}
+
+template <int NV, bool DB = false, bool YB = false>      // DB: delta is bf16; YB: y is written as bf16
 __global__ __launch_bounds__(64 * LN_WAVES) void addln_fwd_kernel(const LnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long wid = (long long)blockIdx.x * LN_WAVES + wave, nw = (long long)gridDim.x * LN_WAVES;
@@ -68,7 +87,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void addln_fwd_kernel(const LnArgs a
             f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
             if (ok[v]) {
                 t = *reinterpret_cast<const f32x4*>(a.x + r * D + c);
-                if (a.delta) t += *reinterpret_cast<const f32x4*>(a.delta + r * D + c);
+                if (a.delta) t += ln_ld4<DB>(a.delta, r * D + c);
                 if (a.xsum) *reinterpret_cast<f32x4*>(a.xsum + r * D + c) = t;
             }
             s[v] = t;
@@ -93,7 +112,8 @@ __global__ __launch_bounds__(64 * LN_WAVES) void addln_fwd_kernel(const LnArgs a
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (s[v][e] - mu) * rs * g[v][e] + bt[v][e];
-                *reinterpret_cast<f32x4*>(a.y + r * D + 4 * (lane + 64 * v)) = o;
+                if constexpr (YB) *reinterpret_cast<ln_u16x4*>(reinterpret_cast<unsigned short*>(a.y) + r * D + 4 * (lane + 64 * v)) = ln_to_bf16(o);
+                else *reinterpret_cast<f32x4*>(a.y + r * D + 4 * (lane + 64 * v)) = o;
             }
         }
         if (lane == 0) {
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void addln_fwd_kernel(const LnArgs a
     }
 }
 
-template <int NV>
+template <int NV, bool GB = false>      // GB: dy is bf16
 __global__ __launch_bounds__(64 * LN_WAVES) void addln_bwd_kernel(const LnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long wid = (long long)blockIdx.x * LN_WAVES + wave, nw = (long long)gridDim.x * LN_WAVES;
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void addln_bwd_kernel(const LnArgs a
             f32x4 xs = {0.0f, 0.0f, 0.0f, 0.0f}, dyv = xs;
             if (ok[v]) {
                 xs = *reinterpret_cast<const f32x4*>(a.x + r * D + c);
-                dyv = *reinterpret_cast<const f32x4*>(a.dy + r * D + c);
+                dyv = ln_ld4<GB>(a.dy, r * D + c);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -152,6 +172,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void addln_bwd_kernel(const LnArgs a
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gy[v][e] - m1 - xh[v][e] * m2);
                 if (a.dres) o += *reinterpret_cast<const f32x4*>(a.dres + r * D + c);
                 *reinterpret_cast<f32x4*>(a.dx + r * D + c) = o;
+                if (a.dx_bf16) *reinterpret_cast<ln_u16x4*>(a.dx_bf16 + r * D + c) = ln_to_bf16(o);
             }
         }
     }
@@ -392,22 +413,33 @@ int ln_dispatch(int D, F&& f) {
 
 extern "C" {
 
-int kanvit_addln_fwd(int64_t M, int D, float eps, const float* x, const float* delta, const float* gamma, const float* beta,
-                     float* xsum, float* y, float* mean, float* rstd, void* stream) {
+int kanvit_addln_fwd_ex(int64_t M, int D, float eps, const float* x, const void* delta, int delta_bf16, const float* gamma, const float* beta,
+                        float* xsum, void* y, int y_bf16, float* mean, float* rstd, void* stream) {
     if (int rc = ln_check("kanvit_addln_fwd", M, D)) return rc;
     if (M == 0) return 0;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return kv_fail(KANVIT_EINVAL, "kanvit_addln_fwd: null argument");
-    if (((uintptr_t)x | (uintptr_t)(delta ? delta : x) | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)(xsum ? xsum : y) | (uintptr_t)y) & 15)
+    if (((uintptr_t)x | (uintptr_t)(delta ? delta : x) | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)(xsum ? xsum : (const float*)y) | (uintptr_t)y) & 15)
         return kv_fail(KANVIT_EINVAL, "kanvit_addln_fwd: pointers must be 16-byte aligned");
     LnArgs a{};
-    a.x = x; a.delta = delta; a.gamma = gamma; a.beta = beta; a.xsum = xsum; a.y = y; a.mean = mean; a.rstd = rstd;
+    a.x = x; a.delta = (const float*)delta; a.gamma = gamma; a.beta = beta; a.xsum = xsum; a.y = (float*)y; a.mean = mean; a.rstd = rstd;
     a.M = M; a.D = D; a.eps = eps;
     hipStream_t st = (hipStream_t)stream;
+    const bool db = delta && delta_bf16, yb = y_bf16 != 0;
     return ln_dispatch(D, [&](auto nv) {
-        hipLaunchKernelGGL((addln_fwd_kernel<decltype(nv)::value>), dim3(ln_grid(M)), dim3(64 * LN_WAVES), 0, st, a);
+        constexpr int NV = decltype(nv)::value;
+        const dim3 grid(ln_grid(M)), block(64 * LN_WAVES);
+        if (db && yb) hipLaunchKernelGGL((addln_fwd_kernel<NV, true, true>), grid, block, 0, st, a);
+        else if (db) hipLaunchKernelGGL((addln_fwd_kernel<NV, true, false>), grid, block, 0, st, a);
+        else if (yb) hipLaunchKernelGGL((addln_fwd_kernel<NV, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((addln_fwd_kernel<NV, false, false>), grid, block, 0, st, a);
         KV_LAUNCH_CHECK("addln_fwd_kernel");
         return 0;
     });
+}
+
+int kanvit_addln_fwd(int64_t M, int D, float eps, const float* x, const float* delta, const float* gamma, const float* beta,
+                     float* xsum, float* y, float* mean, float* rstd, void* stream) {
+    return kanvit_addln_fwd_ex(M, D, eps, x, delta, 0, gamma, beta, xsum, y, 0, mean, rstd, stream);
 }
 
 size_t kanvit_addln_bwd_workspace(int64_t M, int D) {
@@ -418,6 +450,12 @@ size_t kanvit_addln_bwd_workspace(int64_t M, int D) {
 int kanvit_addln_bwd(int64_t M, int D, const float* xsum, const float* gamma, const float* mean, const float* rstd,
                      const float* dy, const float* dres, float* dx, float* dgamma, float* dbeta, void* workspace,
                      size_t workspace_bytes, void* stream) {
+    return kanvit_addln_bwd_ex(M, D, xsum, gamma, mean, rstd, dy, 0, dres, dx, nullptr, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+
+int kanvit_addln_bwd_ex(int64_t M, int D, const float* xsum, const float* gamma, const float* mean, const float* rstd,
+                        const void* dy, int dy_bf16, const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     if (int rc = ln_check("kanvit_addln_bwd", M, D)) return rc;
     if (!dgamma || !dbeta) return kv_fail(KANVIT_EINVAL, "kanvit_addln_bwd: null dgamma/dbeta");
     hipStream_t st = (hipStream_t)stream;
@@ -427,17 +465,19 @@ int kanvit_addln_bwd(int64_t M, int D, const float* xsum, const float* gamma, co
         return 0;
     }
     if (!xsum || !gamma || !mean || !rstd || !dy || !dx) return kv_fail(KANVIT_EINVAL, "kanvit_addln_bwd: null argument");
-    if (((uintptr_t)xsum | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)(dres ? dres : dy) | (uintptr_t)dx | (uintptr_t)workspace) & 15)
+    if (((uintptr_t)xsum | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)(dres ? dres : xsum) | (uintptr_t)dx | (uintptr_t)workspace | (uintptr_t)dx_bf16) & 15)
         return kv_fail(KANVIT_EINVAL, "kanvit_addln_bwd: pointers must be 16-byte aligned");
     const size_t need = kanvit_addln_bwd_workspace(M, D);
     if (!workspace || workspace_bytes < need)
         return kv_fail(KANVIT_ENOMEM, "kanvit_addln_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
     LnArgs a{};
     a.x = xsum; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
-    a.dy = dy; a.dres = dres; a.dx = dx; a.part = (float*)workspace; a.M = M; a.D = D;
+    a.dy = (const float*)dy; a.dres = dres; a.dx = dx; a.dx_bf16 = (unsigned short*)dx_bf16; a.part = (float*)workspace; a.M = M; a.D = D;
     const int grid = ln_grid(M);
     int rc = ln_dispatch(D, [&](auto nv) {
-        hipLaunchKernelGGL((addln_bwd_kernel<decltype(nv)::value>), dim3(grid), dim3(64 * LN_WAVES), sizeof(float) * LN_WAVES * 2 * D, st, a);
+        constexpr int NV = decltype(nv)::value;
+        if (dy_bf16) hipLaunchKernelGGL((addln_bwd_kernel<NV, true>), dim3(grid), dim3(64 * LN_WAVES), sizeof(float) * LN_WAVES * 2 * D, st, a);
+        else hipLaunchKernelGGL((addln_bwd_kernel<NV, false>), dim3(grid), dim3(64 * LN_WAVES), sizeof(float) * LN_WAVES * 2 * D, st, a);
         KV_LAUNCH_CHECK("addln_bwd_kernel");
         return 0;
     });

@@ -85,6 +85,8 @@ SYMBOLS = {
     "kanvit_attn_bwd_workspace": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "kanvit_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_addln_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "kanvit_addln_fwd_ex": (C.c_int, [C.c_int64, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    "kanvit_addln_bwd_ex": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_addln_bwd_workspace": (C.c_size_t, [C.c_int64, C.c_int]),
     "kanvit_addln_bwd": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_relu_bwd_bias_workspace": (C.c_size_t, [C.c_int64, C.c_int]),

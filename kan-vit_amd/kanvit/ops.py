@@ -505,28 +505,36 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = 
 # residual add + LayerNorm (TransformerBlock assembly, reference model.py:31-37)
 # ------------------------------------------------------------------------------------------------
 class _AddLayerNormFn(torch.autograd.Function):
-    """(x, delta | None, gamma, beta) -> (s = x + delta, LayerNorm(s)) in one pass; backward in one pass + a tiny reduce."""
+    """(x, delta | None, gamma, beta) -> (s = x + delta, LayerNorm(s)) in one pass; backward in one pass + a tiny reduce.
+
+    The residual stream (x, s, their gradients) is fp32.  Under torch.autocast(bfloat16) the tensors that come from / go to the
+    feed-forward GEMMs may be bf16 and are read / written as they are (kanvit_addln_*_ex) instead of through cast kernels:
+    `delta` (the previous block's feed-forward output), `y` when `y_bf16` (the feed-forward's input), the gradient arriving
+    on y, and the gradient returned for a bf16 delta (a second, rounded copy of dx written by the same pass)."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, delta, gamma, beta, eps):
-        _require_gpu_f32("x", x)
-        _require_gpu_f32("delta", delta)
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, delta, gamma, beta, eps, y_bf16):
+        if not x.is_cuda:
+            raise KanvitError(f"x is on {x.device}: the kanvit ops run only on an AMD GPU (no CPU fallback)")
         L = _lib.lib()
         D = x.shape[-1]
-        x2 = x.contiguous().view(-1, D)
-        d2 = None if delta is None else delta.contiguous().view(-1, D)
+        x2 = x.float().contiguous().view(-1, D)
+        d2 = None
+        if delta is not None:
+            d2 = (delta if delta.dtype in (torch.float32, torch.bfloat16) else delta.float()).contiguous().view(-1, D)
         M = x2.shape[0]
-        y = torch.empty_like(x2)
+        y = torch.empty(M, D, device=x.device, dtype=torch.bfloat16 if y_bf16 else torch.float32)
         s = torch.empty_like(x2) if d2 is not None else x2
         mean = torch.empty(M, device=x.device, dtype=torch.float32)
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-        g, b = gamma.contiguous(), beta.contiguous()
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
         with torch.cuda.device(x.device):          # launch on x's device and ITS current stream, whatever the ambient device is
-            check(L.kanvit_addln_fwd(M, D, float(eps), _ptr(x2), _ptr(d2), _ptr(g), _ptr(b), _ptr(s) if d2 is not None else None,
-                                     _ptr(y), _ptr(mean), _ptr(rstd), _stream()), "kanvit_addln_fwd")
+            check(L.kanvit_addln_fwd_ex(M, D, float(eps), _ptr(x2), _ptr(d2), int(d2 is not None and d2.dtype == torch.bfloat16), _ptr(g), _ptr(b),
+                                        _ptr(s) if d2 is not None else None, _ptr(y), int(bool(y_bf16)), _ptr(mean), _ptr(rstd), _stream()),
+                  "kanvit_addln_fwd")
         ctx.save_for_backward(s, g, mean, rstd)
-        ctx.has_delta = d2 is not None
+        ctx.delta_dtype = None if d2 is None else d2.dtype
         ctx.shape = x.shape
         return s.view(x.shape), y.view(x.shape)
 
@@ -536,25 +544,33 @@ class _AddLayerNormFn(torch.autograd.Function):
         s, g, mean, rstd = ctx.saved_tensors
         L = _lib.lib()
         M, D = s.shape
-        gy2 = gy.contiguous().view(M, D).float() if gy is not None else torch.zeros_like(s)
+        if gy is None:
+            gy2 = torch.zeros_like(s)
+        else:
+            gy2 = gy.contiguous().view(M, D)
+            if gy2.dtype != torch.bfloat16:
+                gy2 = gy2.float()
         gs2 = None if gs is None else gs.contiguous().view(M, D).float()
         dx = torch.empty_like(s)
+        dxb = torch.empty(M, D, device=s.device, dtype=torch.bfloat16) if ctx.delta_dtype == torch.bfloat16 else None
         dg = torch.empty(D, device=s.device, dtype=torch.float32)
         db = torch.empty(D, device=s.device, dtype=torch.float32)
         nbytes = int(L.kanvit_addln_bwd_workspace(M, D))
         ws = _workspace(nbytes, s.device)
         with torch.cuda.device(s.device):
-            check(L.kanvit_addln_bwd(M, D, _ptr(s), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(gy2), _ptr(gs2), _ptr(dx), _ptr(dg), _ptr(db),
-                                     _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_addln_bwd")
+            check(L.kanvit_addln_bwd_ex(M, D, _ptr(s), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(gy2), int(gy2.dtype == torch.bfloat16), _ptr(gs2),
+                                        _ptr(dx), _ptr(dxb), _ptr(dg), _ptr(db), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_addln_bwd")
         dx = dx.view(ctx.shape)
-        return dx, (dx if ctx.has_delta else None), dg, db, None
+        dd = None if ctx.delta_dtype is None else (dxb.view(ctx.shape) if dxb is not None else dx)
+        return dx, dd, dg, db, None, None
 
 
-def add_layernorm(x: torch.Tensor, delta: Optional[torch.Tensor], norm: torch.nn.LayerNorm):
+def add_layernorm(x: torch.Tensor, delta: Optional[torch.Tensor], norm: torch.nn.LayerNorm, y_bf16: bool = False):
     """(x + delta, norm(x + delta)) -- delta None gives (x, norm(x)).  Shapes the kernel does not cover (last dim not a
-    multiple of 4 or > 1024, non-affine norms) take the stock ops; like every kanvit op it needs CUDA tensors."""
+    multiple of 4 or > 1024, non-affine norms) take the stock ops; like every kanvit op it needs CUDA tensors.
+    y_bf16: write norm(...) as bfloat16 (the caller feeds it to bf16 GEMMs under autocast: no cast pass in between)."""
     D = x.shape[-1]
     if norm.weight is None or norm.bias is None or len(norm.normalized_shape) != 1 or D % 4 or D > 1024 or D < 4:
         s = x if delta is None else x + delta
         return s, norm(s)
-    return _AddLayerNormFn.apply(x, delta, norm.weight, norm.bias, norm.eps)
+    return _AddLayerNormFn.apply(x, delta, norm.weight, norm.bias, norm.eps, bool(y_bf16))

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from attention import MSA, FlashAttention
 from kanvit import ops
-from kanvit.dense import feed_forward, ff_small_supported, ln_feed_forward
+from kanvit.dense import feed_forward, ff_mode, ff_small_supported, ln_feed_forward
 from kanvit.ops import add_layernorm
 from models.cheby import ChebyKANLayer
 from models.effkan import KANLinear
@@ -44,7 +44,10 @@ class TransformerBlock(nn.Module):
             # small geometries: residual add + LN2 + feed-forward in one launch; ln_feed_forward itself falls
             # back to add_layernorm + feed_forward for inputs the fused kernel refuses (dtype, autocast, row count)
             return ln_feed_forward(x, self.attn(h1), self.norm2, self.ff[0], self.ff[2])
-        x, h2 = add_layernorm(x, self.attn(h1), self.norm2)
+        # under bf16 autocast the stock feed-forward GEMMs take bf16 operands: LN2 writes its output as bf16 directly, and the bf16
+        # feed-forward output comes back into the next block's add_layernorm as it is (no cast passes in either direction)
+        ybf = (x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and ff_mode() != "bf16x3")
+        x, h2 = add_layernorm(x, self.attn(h1), self.norm2, y_bf16=ybf)
         # Same three ops as self.ff (Linear -> ReLU(inplace) -> Linear, model.py:25-29), applied to the 2-D
         # (B*N, d) tensor: nn.Linear on 3-D input returns a VIEW, and an in-place ReLU on a view makes autograd
         # insert CopySlices (two full [B*N, 4d] copies per block in backward: 12 ms/step at ViT-B, B=128).
@@ -62,13 +65,14 @@ class _ClsToken(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out, pending):
         ctx.shape = out.shape
+        ctx.pdtype = pending.dtype
         return out[:, 0] + pending[:, 0]
 
     @staticmethod
     def backward(ctx, g):
         full = g.new_zeros(ctx.shape)
         full[:, 0] = g
-        return full, full
+        return full, (full if ctx.pdtype == full.dtype else full.to(ctx.pdtype))      # a bf16 feed-forward output under autocast
 
 
 def _patch_embedding(kind, in_dim, d):
