@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define KANVIT_ABI_VERSION 6
+#define KANVIT_ABI_VERSION 7
 
 /* error codes */
 #define KANVIT_OK 0
@@ -175,7 +175,18 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
  * whose row count is B*(P + prepend_rows).  pos ([P + prepend_rows][O]) and cls ([O]) may be NULL (nothing added /
  * prepend_rows = 0).  Runs on the register-form kernels only: returns KANVIT_EINVAL for shapes they do not cover
  * (O % 32, a feature chunk that does not divide the patch width, FastKAN, which needs u = LayerNorm(x)) -- the caller
- * then uses patchify + kanvit_layer_fwd.  The weight gradient of the layer is kanvit_layer_bwd_weight on the patch rows. */
+ * then uses patchify + kanvit_layer_fwd.  With KANVIT_FLAG_BF16_MFMA the bf16 register-form forward runs the same gather
+ * (workspace as kanvit_layer_fwd_workspace(d) reports, ABI >= 7; without the flag no workspace is needed).
+ *
+ * kanvit_patch_embed_bwd_weight (ABI >= 7): the layer's weight gradient with the same gather on both operands --
+ *     dw[i*GP + j][o] = sum_{b,p} phi_j(patch(b, p)[i]) * dy[b, prepend_rows + p, o]
+ * x rows come from the NCHW images, dY rows from the token-sequence gradient [B][P + prepend_rows][ldy] as the first block's
+ * backward leaves it (class-token rows are stepped over): no transient [B*P, I] patch matrix, no copy of dY.  d as above
+ * (M = B*P, `ldy` = row stride of dy); KANVIT_FLAG_BF16_MFMA and KANVIT_FLAG_SINE_DFREQ as for kanvit_layer_bwd_weight.
+ * kanvit_patch_embed_bwd_weight_ok() (pure host function) says whether the gathering kernels cover the layer: the patch
+ * embeddings VisionTransformer builds (model.py:67-80: ChebyKAN degree 4, efficient-KAN in exact fp32, SineKAN and
+ * FourierKAN at grid 28; I, O multiples of 32, 32-bit element offsets); otherwise the call returns KANVIT_EINVAL and the
+ * caller uses patchify + kanvit_layer_bwd_weight. */
 typedef struct kanvit_patch_desc {
     int32_t C, H, W;         /* image batch is [B][C][H][W], contiguous                                  */
     int32_t n_patches;       /* patches per side: patch = (H / n_patches) x (W / n_patches) pixels       */
@@ -185,6 +196,14 @@ typedef struct kanvit_patch_desc {
 int kanvit_patch_embed_fwd(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* w,
                            const float* bparams, const float* bias, const float* cls, const float* pos, float* y,
                            void* stream);
+int kanvit_patch_embed_fwd_ws(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* w,
+                              const float* bparams, const float* bias, const float* cls, const float* pos, float* y,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int kanvit_patch_embed_bwd_weight_ok(const kanvit_layer_desc* d, const kanvit_patch_desc* p);
+size_t kanvit_patch_embed_bwd_weight_workspace(const kanvit_layer_desc* d, const kanvit_patch_desc* p);
+int kanvit_patch_embed_bwd_weight(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images,
+                                  const float* bparams, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* ---- multi-head attention core ------------------------------------------------------------
  * o = softmax(q k^T * scale) v per (batch, head); replaces attention.py:199-200 (MSA) and

@@ -18,9 +18,12 @@ namespace {
 // for dY.  Partials go to slab[s][g][k][o]; kan_slab_reduce_kernel sums them in order.
 // grid ceil(units * slabs / 4), 256 threads = 4 (slab, wave unit) pairs, unit fastest.
 // =============================================================================================
-template <int FAM, int GP, int NOT, bool BF, int JC = GP>
+// PG (kanvit_patch_embed_bwd_weight): the rows of x are patches of an NCHW image batch and dY carries the class-token rows
+// (PatchWalk, kan_layer_common.h) -- no transient [B*P, I] patch matrix, no copy of dY without its class-token rows.
+template <int FAM, int GP, int NOT, bool BF, int JC = GP, bool PG = false>
 __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
                                                                  int shared, int nbg) {
+    static_assert(!(PG && FAM == KV_RBF), "FastKAN's patch embedding reads u = LayerNorm(x): no gather form");
     constexpr int NJC = (GP + JC - 1) / JC;       // wide bases (G = 28) are contracted in NJC windows of JC basis functions,
                                                   // each its own wave unit (every window regenerates only its own values)
     constexpr bool RBF = (FAM == KV_RBF);
@@ -119,7 +122,38 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         }
     }
     auto tok_of = [&](int blk, int t) -> int { return BF ? (16 * blk + 8 * hf + t) : (2 * (blk * UB + t) + hf); };
+    // patch gather: the walker stands on the first row of the next block to be requested (blocks are requested in order);
+    // rows past the slab take the slab's first row (their dY is zeroed when the block leaves the ring)
+    PatchWalk walk;
+    int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0;
+    if constexpr (PG) {
+        walk.init(a, __builtin_amdgcn_readfirstlane((int)ms));
+        pg_x0 = walk.xoff;
+        pg_dy0 = walk.dyoff;
+        pg_len = __builtin_amdgcn_readfirstlane(len);
+        pg_f = kv_patch_feature_offset(a, f);
+    }
     auto load_block = [&](int q, int blk) {
+        if constexpr (PG) {
+            constexpr int TPB = BF ? 16 : 2 * UB;      // rows of a block: lane half hf takes rows 8hf + t (bf16) / 2t + hf (fp32)
+            int sx[TPB], sdy[TPB];
+#pragma unroll
+            for (int k = 0; k < TPB; ++k) {
+                const bool in = blk * TPB + k < pg_len;
+                sx[k] = in ? walk.xoff : pg_x0;
+                sdy[k] = in ? walk.dyoff : pg_dy0;
+                walk.step();
+            }
+#pragma unroll
+            for (int t = 0; t < NTOK; ++t) {
+                const int k0 = BF ? t : 2 * t, k1 = BF ? 8 + t : 2 * t + 1;
+                const int xo = hf ? sx[k1] : sx[k0], dyr = hf ? sdy[k1] : sdy[k0];
+                rx[q][t] = a.x[xo + pg_f];
+#pragma unroll
+                for (int i = 0; i < NOT; ++i) rdy[q][t][i] = a.dy[dyr + dyo[i]];
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < NTOK; ++t) {
             int tk = tok_of(blk, t);
@@ -251,8 +285,9 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
 // Everything else as above: wave units (basis group, column-tile set, window, feature block) flattened over the grid,
 // compile-time window start, scalar wave index, operands prefetched PD blocks ahead, slabs + ordered reduce.
 // =============================================================================================
-template <int FAM, int GP, int JC, int NC>
+template <int FAM, int GP, int JC, int NC, bool PG = false>
 __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg, int shared, int nbg) {
+    static_assert(!(PG && FAM == KV_RBF), "FastKAN's patch embedding reads u = LayerNorm(x): no gather form");
     constexpr int NJC = (GP + JC - 1) / JC;
     static_assert(GP % JC == 0 && (NJC == 3 || NJC == 1), "whole windows: three of three values (B-spline) or all nine (FastKAN)");
     constexpr bool RBF = (FAM == KV_RBF);
@@ -316,7 +351,34 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
         float rx[PD][UB], rdy[PD][UB][NC];
         float2 ru[RBF ? PD : 1][RBF ? UB : 1];      // FastKAN: u (in .x), or the token's (mean, rstd)
         auto tok_of = [&](int blk, int t) -> int { return 4 * (blk * UB + t) + tq; };
+        PatchWalk walk;                       // patch gather: see kan_bwd_weight_reg_kernel
+        int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0;
+        if constexpr (PG) {
+            static_assert(!PG || UB == 1, "one step of four rows per block");
+            walk.init(a, __builtin_amdgcn_readfirstlane((int)ms));
+            pg_x0 = walk.xoff;
+            pg_dy0 = walk.dyoff;
+            pg_len = __builtin_amdgcn_readfirstlane(len);
+            pg_f = kv_patch_feature_offset(a, f);
+        }
         auto load_block = [&](int q, int blk) {
+            if constexpr (PG) {
+                int sx[4], sdy[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = blk * 4 + k < pg_len;
+                    sx[k] = in ? walk.xoff : pg_x0;
+                    sdy[k] = in ? walk.dyoff : pg_dy0;
+                    walk.step();
+                }
+                const bool t1 = tq & 1, t2 = tq & 2;          // lane group tq takes row tq of the block
+                const int xo = t2 ? (t1 ? sx[3] : sx[2]) : (t1 ? sx[1] : sx[0]);
+                const int dyr = t2 ? (t1 ? sdy[3] : sdy[2]) : (t1 ? sdy[1] : sdy[0]);
+                rx[q][0] = a.x[xo + pg_f];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) rdy[q][0][i] = a.dy[dyr + dyo[i]];
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < UB; ++t) {
                 int tk = tok_of(blk, t);
@@ -407,34 +469,49 @@ __global__ __launch_bounds__(256) void kan_slab_reduce_kernel(const float* __res
     }
 }
 
-template <int FAM, int GP, int NOT, int JC = GP, bool HAS_BF = true>
-int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+template <int FAM, int GP, int NOT, bool BF, int JC, bool PG>
+int launch_bwd_weight_reg_one(LayerArgs& a, const BwRegPlan& p, hipStream_t st) {
     const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
     dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
     const size_t lds = a.ln ? (size_t)4 * p.rows_per_slab * sizeof(float2) : 0;      // four wave-private (mean, rstd) strips
-    if constexpr (HAS_BF) {
-        if (bf) {
-            if (lds > 64 * 1024) KV_ALLOW_LDS(160 * 1024, (kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>));
-            hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, true, JC>), grid, dim3(256), lds, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
-            KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
-            return 0;
-        }
-    } else if (bf) {
-        return kv_fail(KANVIT_EINVAL, "internal: this register weight-gradient instantiation has no bf16 form");
-    }
-    {
-        if (lds > 64 * 1024) KV_ALLOW_LDS(160 * 1024, (kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>));
-        hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, false, JC>), grid, dim3(256), lds, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
-    }
+    if (lds > 64 * 1024) KV_ALLOW_LDS(160 * 1024, (kan_bwd_weight_reg_kernel<FAM, GP, NOT, BF, JC, PG>));
+    hipLaunchKernelGGL((kan_bwd_weight_reg_kernel<FAM, GP, NOT, BF, JC, PG>), grid, dim3(256), lds, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     KV_LAUNCH_CHECK("kan_bwd_weight_reg_kernel");
     return 0;
 }
 
-template <int FAM, int GP, int JC, int NC>
+// HAS_PG: the instantiation also exists in its patch-gather form (the patch-embedding layers the model builds: kv_bwd_weight_reg_pg_ok)
+template <int FAM, int GP, int NOT, int JC = GP, bool HAS_BF = true, bool HAS_PG = false>
+int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+    if (bf && !HAS_BF) return kv_fail(KANVIT_EINVAL, "internal: this register weight-gradient instantiation has no bf16 form");
+    if (a.pg && !HAS_PG) return kv_fail(KANVIT_EINVAL, "internal: this register weight-gradient instantiation has no patch-gather form");
+    if constexpr (HAS_PG) {
+        if (a.pg) {
+            if constexpr (HAS_BF) {
+                if (bf) return launch_bwd_weight_reg_one<FAM, GP, NOT, true, JC, true>(a, p, st);
+            }
+            return launch_bwd_weight_reg_one<FAM, GP, NOT, false, JC, true>(a, p, st);
+        }
+    }
+    if constexpr (HAS_BF) {
+        if (bf) return launch_bwd_weight_reg_one<FAM, GP, NOT, true, JC, false>(a, p, st);
+    }
+    return launch_bwd_weight_reg_one<FAM, GP, NOT, false, JC, false>(a, p, st);
+}
+
+template <int FAM, int GP, int JC, int NC, bool HAS_PG = false>
 int launch_bwd_weight_reg16(LayerArgs& a, const BwRegPlan& p, hipStream_t st) {
     const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
     dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
-    hipLaunchKernelGGL((kan_bwd_weight_reg16_kernel<FAM, GP, JC, NC>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+    if (a.pg && !HAS_PG) return kv_fail(KANVIT_EINVAL, "internal: this 16-row weight-gradient instantiation has no patch-gather form");
+    if constexpr (HAS_PG) {
+        if (a.pg) {
+            hipLaunchKernelGGL((kan_bwd_weight_reg16_kernel<FAM, GP, JC, NC, true>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+            KV_LAUNCH_CHECK("kan_bwd_weight_reg16_kernel");
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((kan_bwd_weight_reg16_kernel<FAM, GP, JC, NC, false>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     KV_LAUNCH_CHECK("kan_bwd_weight_reg16_kernel");
     return 0;
 }
@@ -443,22 +520,22 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
     if (p.t16) {
         if (bf || (family != KANVIT_BSPLINE && family != KANVIT_RBF)) return kv_fail(KANVIT_EINVAL, "internal: 16-row weight-gradient dispatch");
         if (family == KANVIT_RBF) return launch_bwd_weight_reg16<KV_RBF, 9, 9, 4>(a, p, st);
-        return p.nt == 12 ? launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 12>(a, p, st) : launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 4>(a, p, st);
+        return p.nt == 12 ? launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 12, true>(a, p, st) : launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 4, true>(a, p, st);
     }
     switch (family) {
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
-        case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3>(a, p, bf, st);
+        case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1, 5, true, true>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3, 5, true, true>(a, p, bf, st);
         case KANVIT_BSPLINE:      // exact fp32 only (the plan refuses bf16 mode: there the LDS-tile bf16 kernel runs)
             return p.nt == 3 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 3, 5, false>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 5, false>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:
             if (a.flags & KANVIT_FLAG_SINE_DFREQ) {      // the x * cos operand (d loss / d freq through a weight-gradient pass; kanvit.h)
-                if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE_DF, 28, 4, 4>(a, p, bf, st);
+                if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE_DF, 28, 4, 4, true, true>(a, p, bf, st);
                 return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE_DF, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE_DF, 5, 2>(a, p, bf, st);
             }
-            if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE, 28, 4, 4>(a, p, bf, st);
+            if (a.GP == 28) return launch_bwd_weight_reg<KV_SINE, 28, 4, 4, true, true>(a, p, bf, st);
             return a.GP == 4 ? launch_bwd_weight_reg<KV_SINE, 4, 2>(a, p, bf, st) : launch_bwd_weight_reg<KV_SINE, 5, 2>(a, p, bf, st);
-        case KANVIT_FOURIER: return launch_bwd_weight_reg<KV_FOURIER, 56, 4, 4>(a, p, bf, st);
+        case KANVIT_FOURIER: return launch_bwd_weight_reg<KV_FOURIER, 56, 4, 4, true, true>(a, p, bf, st);
         default: return kv_fail(KANVIT_EINVAL, "internal: register weight-gradient dispatch");
     }
 }
@@ -574,6 +651,19 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
 }
 
 int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) { return dispatch_bwd_weight_reg(family, a, p, bf, st); }
+
+// the plans whose kernels exist in the patch-gather form (dispatch_bwd_weight_reg's HAS_PG instantiations): the patch-embedding
+// layers VisionTransformer builds (model.py:67-80: ChebyKAN degree 4, efficient-KAN, SineKAN / FourierKAN at grid 28)
+bool kv_bwd_weight_reg_pg_ok(const kanvit_layer_desc* d, const BwRegPlan& p) {
+    if (!p.ok || d->groups != 1) return false;
+    if (p.t16) return d->family == KANVIT_BSPLINE;
+    switch (d->family) {
+        case KANVIT_CHEBY: return p.gp == 5 && (p.nt == 3 || p.nt == 1);
+        case KANVIT_SINE: return p.gp == 28;
+        case KANVIT_FOURIER: return p.gp == 56;
+        default: return false;
+    }
+}
 
 // dw[e] = sum over the `slabs` partial slabs (each `total` floats), in slab order
 int kv_slab_reduce(const float* slab, float* dw, long long total, int slabs, hipStream_t st) {

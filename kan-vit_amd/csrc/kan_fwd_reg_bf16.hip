@@ -35,8 +35,11 @@ __global__ __launch_bounds__(256) void kan_pack_w_fwd_reg_kernel(const float* __
     *reinterpret_cast<u32x4*>(wb + e * 8) = out;
 }
 
-template <int FAM, int GP, int NT, int NSH, int ICH>
+// PG (kanvit_patch_embed_fwd_ws): rows gathered from the NCHW images, position embedding added and class-token rows written
+// in the epilogue -- the prologue / epilogue of kan_fwd_reg_kernel's patch form on the bf16 matrix cores.
+template <int FAM, int GP, int NT, int NSH, int ICH, bool PG = false>
 __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a) {
+    static_assert(!(PG && (FAM == KV_RBF || NSH != 1)), "patch gather: one plain layer, no LayerNorm'ed second input");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 32 * NT;
     constexpr int WROW = NSH * BN;
@@ -77,6 +80,21 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
         }
     }
 
+    // patch gather: the lane's ICH features of a chunk are ICH consecutive pixels of one image line (host-checked: the chunk
+    // divides the patch width); chunks are visited in order, so the position inside the patch advances incrementally
+    int pg_ix = 0, pg_iy = 0, pg_off = 0, pg_pw = 0, pg_ph = 0;
+    if constexpr (PG) {
+        const int P = a.pg_n * a.pg_n;
+        pg_ph = a.pg_H / a.pg_n;
+        pg_pw = a.pg_W / a.pg_n;
+        const long long m = m0 + (row_ok ? row : 0);
+        const long long smp = m / P;
+        const int pidx = (int)(m - smp * P);
+        const int py = pidx / a.pg_n, px = pidx - py * a.pg_n;
+        xrow = a.x + ((smp * a.pg_C) * a.pg_H + (long long)py * pg_ph) * a.pg_W + px * pg_pw;      // patch origin in channel 0
+        pg_ix = pg_off = hf * ICH;
+    }
+
     u32x4 wreg[NSH][WQ];
     auto load_w = [&](int c) {
 #pragma unroll
@@ -112,10 +130,23 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
 
     float xv[ICH], uv[ICH];
     auto load_x = [&](int c) {
+        const float* xs = PG ? xrow + pg_off : xrow + c * IC;
+        if constexpr (PG) {                       // next chunk: IC pixels further along the line, then next line, then next channel
+            pg_ix += IC;
+            pg_off += IC;
+            if (pg_ix >= pg_pw) {
+                pg_ix -= pg_pw;
+                pg_off += a.pg_W - pg_pw;
+                if (++pg_iy == pg_ph) {
+                    pg_iy = 0;
+                    pg_off += (a.pg_H - pg_ph) * a.pg_W;
+                }
+            }
+        }
         if constexpr (ICH % 4 == 0) {
 #pragma unroll
             for (int j4 = 0; j4 < ICH / 4; ++j4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + c * IC + 4 * j4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xs + 4 * j4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xv[4 * j4 + e] = v[e];
                 if (RBF && !a.ln) {
@@ -127,7 +158,7 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
         } else {
 #pragma unroll
             for (int e = 0; e < ICH; ++e) {
-                xv[e] = xrow[c * IC + e];
+                xv[e] = xs[e];
                 if (RBF && !a.ln) uv[e] = urow[c * IC + e];
             }
         }
@@ -214,6 +245,20 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
 
     float* T_w = smem + wave * 32 * TS;
     const int er = lane >> 3, ec = (lane & 7) * 4;
+    // patch form: the rows this lane STORES (er + 8q of the wave's strip) sit pg_pre rows per image further down, get their
+    // position-embedding row added, and the first patch of an image also writes the image's class-token row cls + pos[0]
+    long long pg_yrow[PG ? 4 : 1];
+    int pg_pidx[PG ? 4 : 1];
+    if constexpr (PG) {
+        const int P = a.pg_n * a.pg_n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long m = m0 + wave * 32 + er + q * 8;
+            const long long smp = m / P;
+            pg_pidx[q] = (int)(m - smp * P);
+            pg_yrow[q] = m + (smp + 1) * a.pg_pre;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NSH * NT; ++t) {
         const int p = t / NT, nt = t - p * NT;
@@ -221,15 +266,27 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) T_w[kv_acc_row(r, hf) * TS + l31] = acc[t][r];
         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)g * a.O + n0 + nt * 32 + ec);
-        float* yt = a.y + (m0 + wave * 32) * a.ldy + (long long)g * a.O + n0 + nt * 32 + ec;
+        const int col = n0 + nt * 32 + ec;
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + (long long)g * a.O + col);
+        float* yt = a.y + (m0 + wave * 32) * a.ldy + (long long)g * a.O + col;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int rr = er + q * 8;
             if (wave * 32 + rr < mrem) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(T_w + rr * TS + ec);
                 v += bv;
-                *reinterpret_cast<f32x4*>(yt + (long long)rr * a.ldy) = v;
+                if constexpr (PG) {
+                    if (a.pos) v += *reinterpret_cast<const f32x4*>(a.pos + (long long)(pg_pidx[q] + a.pg_pre) * a.O + col);
+                    float* yp = a.y + pg_yrow[q] * a.ldy + col;
+                    *reinterpret_cast<f32x4*>(yp) = v;
+                    if (a.pg_pre && a.cls && pg_pidx[q] == 0) {
+                        f32x4 cv = *reinterpret_cast<const f32x4*>(a.cls + col);
+                        if (a.pos) cv += *reinterpret_cast<const f32x4*>(a.pos + col);
+                        *reinterpret_cast<f32x4*>(yp - a.ldy) = cv;
+                    }
+                } else {
+                    *reinterpret_cast<f32x4*>(yt + (long long)rr * a.ldy) = v;
+                }
             }
         }
     }
@@ -412,7 +469,7 @@ int launch_fwd_reg_bf16(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t
     if constexpr (ICH == 8 && (FAM == KV_LINEAR || FAM == KV_CHEBY)) {     // the families whose basis fragments fit the register file
         const size_t wlds = (size_t)p.nch * p.vs * 2 * 32 * NT * NSH * 16 + sizeof(float) * 32 * NT * NSH;
         const int gx = (a.groups / NSH) * (a.O / (32 * NT));
-        if (wlds <= 150 * 1024 && p.nch == 4 && a.M >= 4096 && gx <= N_CU && !((uintptr_t)a.y & 15) && !kv_config().no_ws) {
+        if (wlds <= 150 * 1024 && p.nch == 4 && a.M >= 4096 && gx <= N_CU && !((uintptr_t)a.y & 15) && !kv_config().no_ws && !a.pg) {
             KV_ALLOW_LDS(160 * 1024, (kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>));
             const long long ntiles = (a.M + KV_WS_THREADS / 2 - 1) / (KV_WS_THREADS / 2);
             long long py = N_CU / gx;             // one work-group per CU (the image fills the LDS)
@@ -423,8 +480,17 @@ int launch_fwd_reg_bf16(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t
             return 0;
         }
     }
-    KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>));
     dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
+    if (a.pg) {         // fused patch embedding: one wide layer (NT = 4), the families whose patch embedding the model builds
+        if constexpr (NT == 4 && NSH == 1 && FAM != KV_RBF && FAM != KV_LINEAR) {
+            KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH, true>));
+            hipLaunchKernelGGL((kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH, true>), grid, dim3(256), p.lds, st, a);
+            KV_LAUNCH_CHECK("kan_fwd_reg_bf16_kernel (patch gather)");
+            return 0;
+        }
+        return 1;       // not covered
+    }
+    KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>));
     hipLaunchKernelGGL((kan_fwd_reg_bf16_kernel<FAM, GP, NT, NSH, ICH>), grid, dim3(256), p.lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_reg_bf16_kernel");
     return 0;

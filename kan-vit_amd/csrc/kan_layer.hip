@@ -264,8 +264,9 @@ static void patch_args(LayerArgs& a, const kanvit_patch_desc* p, const float* cl
     a.ldx = a.I;                         // unused by the gather; keeps the alignment checks of the dispatcher meaningful
 }
 
-int kanvit_patch_embed_fwd(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* w,
-                           const float* bparams, const float* bias, const float* cls, const float* pos, float* y, void* stream) {
+int kanvit_patch_embed_fwd_ws(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* w,
+                              const float* bparams, const float* bias, const float* cls, const float* pos, float* y,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = validate(d, "kanvit_patch_embed_fwd")) return rc;
     if (int rc = patch_validate(d, p, "kanvit_patch_embed_fwd")) return rc;
     if (d->M == 0) return 0;
@@ -282,11 +283,85 @@ int kanvit_patch_embed_fwd(const kanvit_layer_desc* d, const kanvit_patch_desc* 
     a.y = y;
     patch_args(a, p, cls, pos);
     hipStream_t st = (hipStream_t)stream;
-    const int rc = (kv_config().no_reg || d->family == KANVIT_RBF) ? 1 : kv_try_fwd_reg(d->family, a, st);
+    int rc = 1;
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16) {
+        // bf16 matrix cores: the register-form forward in its patch form (one wide layer: four column tiles per work-group; a
+        // lane's feature chunk must be consecutive pixels of one image line)
+        const FwdRegBf16Plan pr = plan_fwd_reg_bf16(d);
+        const int pw = p->W / p->n_patches;
+        if (pr.ok && pr.nt == 4 && pr.nsh == 1 && d->family != KANVIT_RBF && d->family != KANVIT_LINEAR && pw % (2 * pr.ich) == 0 &&
+            (pr.ich < 4 || (p->W & 3) == 0) && !(((uintptr_t)y | (uintptr_t)(bias ? bias : w) | (uintptr_t)(bparams ? bparams : w)) & 15)) {
+            if (!workspace || workspace_bytes < pr.ws_bytes || ((uintptr_t)workspace & 15))
+                return kv_fail(KANVIT_ENOMEM, "kanvit_patch_embed_fwd: workspace %zu bytes < required %zu (or not 16-byte aligned)",
+                               workspace_bytes, pr.ws_bytes);
+            rc = kv_fwd_reg_bf16(d->family, a, pr, workspace, st);
+        }
+    } else {
+        rc = (kv_config().no_reg || d->family == KANVIT_RBF) ? 1 : kv_try_fwd_reg(d->family, a, st);
+    }
     if (rc == 1)
         return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_fwd: shape not covered by the fused kernel (O %% 32, patch width %% chunk, "
                                       "basis size); use patchify + kanvit_layer_fwd");
     return rc;
+}
+
+int kanvit_patch_embed_fwd(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* w,
+                           const float* bparams, const float* bias, const float* cls, const float* pos, float* y, void* stream) {
+    if (d && (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16)
+        return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_fwd: KANVIT_FLAG_BF16_MFMA needs a workspace (kanvit_patch_embed_fwd_ws)");
+    return kanvit_patch_embed_fwd_ws(d, p, images, w, bparams, bias, cls, pos, y, nullptr, 0, stream);
+}
+
+// Weight gradient of the patch-embedding layer with the same gather: x rows from the NCHW images, dY rows from the token-sequence
+// gradient [B][P + prepend_rows][ldy] (the class-token rows are stepped over) -- no transient patch matrix, no dY copy.
+int kanvit_patch_embed_bwd_weight_ok(const kanvit_layer_desc* d, const kanvit_patch_desc* p) {
+    if (!d || !p || gp_of(d) < 1 || d->groups != 1 || d->x_group_mod != 1 || d->I < 1 || d->O < 1 || d->M < 1) return 0;
+    if (p->C < 1 || p->H < 1 || p->W < 1 || p->n_patches < 1 || p->H % p->n_patches || p->W % p->n_patches) return 0;
+    if (p->prepend_rows != 0 && p->prepend_rows != 1) return 0;
+    const long long P = (long long)p->n_patches * p->n_patches;
+    if (d->I != (long long)p->C * (p->H / p->n_patches) * (p->W / p->n_patches) || d->M % P) return 0;
+    const long long B = d->M / P;
+    // 32-bit element offsets from the image base / the dY base
+    if (B * p->C * p->H * p->W >= (1LL << 31) || (d->M + B * p->prepend_rows + 1) * d->ldy >= (1LL << 31)) return 0;
+    if (d->family == KANVIT_RBF || kv_tiny_ok(d)) return 0;
+    return kv_bwd_weight_reg_pg_ok(d, plan_bwd_weight_reg(d)) ? 1 : 0;
+}
+
+size_t kanvit_patch_embed_bwd_weight_workspace(const kanvit_layer_desc* d, const kanvit_patch_desc* p) {
+    if (!kanvit_patch_embed_bwd_weight_ok(d, p)) return 0;
+    return plan_bwd_weight_reg(d).ws_bytes;
+}
+
+int kanvit_patch_embed_bwd_weight(const kanvit_layer_desc* d, const kanvit_patch_desc* p, const float* images, const float* bparams,
+                                  const float* dy, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = validate(d, "kanvit_patch_embed_bwd_weight")) return rc;
+    if (int rc = patch_validate(d, p, "kanvit_patch_embed_bwd_weight")) return rc;
+    if (!dw) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: null dw");
+    if (d->M == 0) {
+        KV_HIP_CHECK(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->I * gp_of(d) * d->O, (hipStream_t)stream));
+        return 0;
+    }
+    if (!images || !dy) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: null images/dy");
+    if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: family %d needs bparams", d->family);
+    if (!kanvit_patch_embed_bwd_weight_ok(d, p))
+        return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: layer / geometry not covered by the gathering weight-gradient kernels "
+                                      "(kanvit_patch_embed_bwd_weight_ok); use patchify + kanvit_layer_bwd_weight");
+    const BwRegPlan pr = plan_bwd_weight_reg(d);
+    if (pr.ws_bytes > 0 && (!workspace || workspace_bytes < pr.ws_bytes))
+        return kv_fail(KANVIT_ENOMEM, "kanvit_patch_embed_bwd_weight: workspace %zu bytes < required %zu", workspace_bytes, pr.ws_bytes);
+    LayerArgs a = base_args(d);
+    a.x = images;
+    a.bp = bparams;
+    a.dy = dy;
+    patch_args(a, p, nullptr, nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
+    a.rows_per_split = pr.rows_per_slab;
+    a.msplit = pr.slabs;
+    a.slab = (pr.slabs > 1) ? (float*)workspace : dw;
+    if (int rc = kv_bwd_weight_reg(d->family, a, pr, bf, st)) return rc;
+    if (pr.slabs > 1) return kv_slab_reduce((const float*)workspace, dw, (long long)a.K * d->O, pr.slabs, st);
+    return 0;
 }
 
 int kanvit_layer_sine_dfreq_ok(const kanvit_layer_desc* d) {

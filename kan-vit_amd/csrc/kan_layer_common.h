@@ -96,6 +96,50 @@ __device__ __forceinline__ void kv_ln_row_stats(const float* __restrict__ xh, in
     rstd = rsqrtf(q / (float)I + eps);
 }
 
+// Patch rows that exist only as an NCHW image batch (kanvit_patch_embed_*; model.py:111-126): row m = (image m / P, patch
+// m % P).  The weight-gradient kernels visit the rows of a slab in order, a few per step, so the walker keeps the position
+// of ONE row -- element offset of the patch origin (channel 0) from the image base, element offset of the row's dY row
+// from the dY base (dY has pg_pre extra rows per image in front of the patch tokens) -- and advances it row by row: adds and
+// compares on wave-uniform values (the scalar unit), no division after init().  Feature i = (c, iy, ix) of a patch adds
+// the lane constant kv_patch_feature_offset().
+struct PatchWalk {
+    int px, py, xoff, dyoff;
+    int n, pw, line_wrap, img_wrap, ldy, pre_ldy;
+    __device__ __forceinline__ void init(const LayerArgs& a, int m) {
+        n = a.pg_n;
+        const int P = n * n, ph = a.pg_H / n;
+        pw = a.pg_W / n;
+        const int smp = m / P, pidx = m - smp * P;
+        py = pidx / n;
+        px = pidx - py * n;
+        xoff = (smp * a.pg_C * a.pg_H + py * ph) * a.pg_W + px * pw;
+        ldy = (int)a.ldy;
+        pre_ldy = a.pg_pre * ldy;
+        dyoff = (m + (smp + 1) * a.pg_pre) * ldy;
+        line_wrap = ph * a.pg_W - n * pw;                       // last patch of a patch row -> first patch of the next one
+        img_wrap = (a.pg_C * a.pg_H - n * ph) * a.pg_W;         // last patch of an image -> first patch of the next image
+    }
+    __device__ __forceinline__ void step() {
+        xoff += pw;
+        dyoff += ldy;
+        if (++px == n) {
+            px = 0;
+            xoff += line_wrap;
+            if (++py == n) {
+                py = 0;
+                xoff += img_wrap;
+                dyoff += pre_ldy;
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ int kv_patch_feature_offset(const LayerArgs& a, int f) {
+    const int ph = a.pg_H / a.pg_n, pw = a.pg_W / a.pg_n;
+    const int c = f / (ph * pw), r = f - c * (ph * pw), iy = r / pw, ix = r - iy * pw;
+    return (c * a.pg_H + iy) * a.pg_W + ix;
+}
+
 __device__ __forceinline__ int kv_pow2_ge(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -206,3 +250,4 @@ int kv_bwd_input_reg_bf16(int family, LayerArgs& a, const BwdRegBf16Plan& p, hip
 BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d);
 int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st);
 int kv_slab_reduce(const float* slab, float* dw, long long total, int slabs, hipStream_t st);
+bool kv_bwd_weight_reg_pg_ok(const kanvit_layer_desc* d, const BwRegPlan& p);      // the plan's kernel exists in the patch-gather form

@@ -81,6 +81,10 @@ SYMBOLS = {
     "kanvit_layer_bwd_weight_workspace": (C.c_size_t, [C.POINTER(LayerDesc)]),
     "kanvit_layer_bwd_weight": (C.c_int, _LAYER_BWD_W),
     "kanvit_patch_embed_fwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(PatchDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "kanvit_patch_embed_fwd_ws": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(PatchDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kanvit_patch_embed_bwd_weight_ok": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(PatchDesc)]),
+    "kanvit_patch_embed_bwd_weight_workspace": (C.c_size_t, [C.POINTER(LayerDesc), C.POINTER(PatchDesc)]),
+    "kanvit_patch_embed_bwd_weight": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(PatchDesc), _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
     "kanvit_attn_bwd_workspace": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "kanvit_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -118,7 +122,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.kanvit_abi_version() != 6:
+        if handle.kanvit_abi_version() != 7:
             raise KanvitError("libkanvit.so ABI version mismatch")
         _lib = handle
     return _lib
@@ -134,13 +138,15 @@ def py_switches() -> dict:
       no_ff_small  KANVIT_NO_FF_SMALL     stock GEMMs instead of the fused small feed-forward (csrc/ff_small.hip)
       no_lnff      KANVIT_NO_LNFF         separate add+LayerNorm in front of the fused small feed-forward
       no_ff_epi    KANVIT_NO_FF_EPILOGUE  stock threshold_backward + sum(0) instead of the fused ReLU-mask + bias-gradient pass
-      no_dfreq_w   KANVIT_NO_DFREQ_W      SineKAN d loss / d freq always through the input-gradient kernel (ops._kan_backward)"""
+      no_dfreq_w   KANVIT_NO_DFREQ_W      SineKAN d loss / d freq always through the input-gradient kernel (ops._kan_backward)
+      no_patch_bw  KANVIT_NO_PATCH_BW     patch-embedding weight gradient on a transient patch matrix instead of gathering from the images"""
     global _py_switches
     if _py_switches is None:
         _py_switches = {"ff": os.environ.get("KANVIT_FF", ""), "no_ff_small": int(bool(os.environ.get("KANVIT_NO_FF_SMALL"))),
                         "no_lnff": int(bool(os.environ.get("KANVIT_NO_LNFF"))),
                         "no_ff_epi": int(bool(os.environ.get("KANVIT_NO_FF_EPILOGUE"))),
-                        "no_dfreq_w": int(bool(os.environ.get("KANVIT_NO_DFREQ_W")))}
+                        "no_dfreq_w": int(bool(os.environ.get("KANVIT_NO_DFREQ_W"))),
+                        "no_patch_bw": int(bool(os.environ.get("KANVIT_NO_PATCH_BW")))}
     return _py_switches
 
 
@@ -149,7 +155,7 @@ def active_config() -> str:
     library's (KvConfig) followed by the Python-side ones (py_switches)."""
     ps = py_switches()
     alt = f" lib={LIB_PATH}" if os.environ.get("KANVIT_LIB") else ""
-    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']} py_no_ff_epi={ps['no_ff_epi']} py_no_dfreq_w={ps['no_dfreq_w']}" + alt
+    return lib().kanvit_config().decode() + f" py_ff={ps['ff'] or 'default'} py_no_ff_small={ps['no_ff_small']} py_no_lnff={ps['no_lnff']} py_no_ff_epi={ps['no_ff_epi']} py_no_dfreq_w={ps['no_dfreq_w']} py_no_patch_bw={ps['no_patch_bw']}" + alt
 
 
 def reload_config() -> str:

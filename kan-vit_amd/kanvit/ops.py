@@ -168,12 +168,36 @@ class _KanLayerFn(torch.autograd.Function):
                              ctx.has_u, ctx.has_bias) + (None,)
 
 
-def _kan_backward(cfg: "LayerCfg", x, u, w, bparams, dy, needs, has_u, has_bias):
-    """Gradients of one fused KAN launch w.r.t. (x, u, w, bparams, bias): the C-ABI input-gradient and weight-gradient calls."""
-    M, ldx = x.shape
+def _kan_backward(cfg: "LayerCfg", x, u, w, bparams, dy, needs, has_u, has_bias, patch=None):
+    """Gradients of one fused KAN launch w.r.t. (x, u, w, bparams, bias): the C-ABI input-gradient and weight-gradient calls.
+
+    patch = (PatchDesc, M): x is the NCHW image batch and dy the token-sequence gradient [B, P + pre, O]; the weight-gradient
+    kernels gather both (kanvit_patch_embed_bwd_weight: no patch matrix, no dY copy).  Only weight-side gradients then."""
+    if patch is not None:
+        pd, M = patch
+        ldx = cfg.I
+        assert not (needs[0] or needs[1]), "the patch form has no input gradient"
+    else:
+        pd = None
+        M, ldx = x.shape
     need_x, need_u, need_w, need_bp, need_b = needs
     d = _desc(cfg, M, ldx, cfg.groups * cfg.I, cfg.groups * cfg.O, 0 if bparams is None else bparams.shape[1])
     L = _lib.lib()
+
+    def weight_pass(desc, out, tag):
+        if pd is not None:
+            nbytes = int(L.kanvit_patch_embed_bwd_weight_workspace(C.byref(desc), C.byref(pd)))
+            ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+            with _timed(tag, *_layer_cost(cfg, M, "bwd_weight")):
+                check(L.kanvit_patch_embed_bwd_weight(C.byref(desc), C.byref(pd), _ptr(x), _ptr(bparams), _ptr(dy), _ptr(out),
+                                                      _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_patch_embed_bwd_weight")
+            return
+        nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(desc)))
+        ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+        with _timed(tag, *_layer_cost(cfg, M, "bwd_weight")):
+            check(L.kanvit_layer_bwd_weight(C.byref(desc), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(out),
+                                            _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
+
     dx = du = dw = dbp = db = None
     sine_freq = cfg.family == SINE and need_bp
     # SineKAN's trainable freq (models/sinekan.py:60): d loss / d freq_g = sum_{m,i} x cos(x f_g + p_ig) dPhi[m,i,g] falls out of the
@@ -181,9 +205,11 @@ def _kan_backward(cfg: "LayerCfg", x, u, w, bparams, dy, needs, has_u, has_bias)
     # sum_{i,o} w[(i,g),o] Q[(i,g),o] with Q = a weight-gradient pass over the operand x cos(.) (KANVIT_FLAG_SINE_DFREQ) -- the faster
     # of the two contractions at G = 28 (8.6 instead of 13.9 ms at ViT-B).
     freq_via_w = False
-    if sine_freq and not need_x and not _lib.py_switches()["no_dfreq_w"]:
+    if sine_freq and not need_x and (pd is not None or not _lib.py_switches()["no_dfreq_w"]):
         with torch.cuda.device(x.device):
             freq_via_w = bool(L.kanvit_layer_sine_dfreq_ok(C.byref(d)))
+    if pd is not None and sine_freq and not freq_via_w:
+        raise KanvitError("patch form: SineKAN's frequency gradient needs the register weight-gradient kernel")
     with torch.cuda.device(x.device):
         if need_x or (need_u and has_u) or (sine_freq and not freq_via_w):
             dx = torch.empty_like(x)
@@ -210,25 +236,19 @@ def _kan_backward(cfg: "LayerCfg", x, u, w, bparams, dy, needs, has_u, has_bias)
                 dbp[:, :cfg.G] = dpart.sum(0)
         if need_w:
             dw = torch.empty_like(w)
-            nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(d)))
-            ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-            with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_weight" + ("_bf16" if cfg.flags & 1 else ""),
-                        *_layer_cost(cfg, M, "bwd_weight")):
-                check(L.kanvit_layer_bwd_weight(C.byref(d), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(dw),
-                                                _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight")
+            weight_pass(d, dw, ("qkv" if cfg.groups > 1 else "layer") + "_bwd_weight" + ("_bf16" if cfg.flags & 1 else ""))
         if freq_via_w:
             dq = LayerDesc(*[getattr(d, f) for f, _ in LayerDesc._fields_])
             dq.flags = cfg.flags | _lib.FLAG_SINE_DFREQ
             q = torch.empty_like(w)
-            nbytes = int(L.kanvit_layer_bwd_weight_workspace(C.byref(dq)))
-            ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-            with _timed(("qkv" if cfg.groups > 1 else "layer") + "_bwd_freq" + ("_bf16" if cfg.flags & 1 else ""), *_layer_cost(cfg, M, "bwd_weight")):
-                check(L.kanvit_layer_bwd_weight(C.byref(dq), _ptr(x), _ptr(u), _ptr(bparams), _ptr(dy), _ptr(q),
-                                                _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_layer_bwd_weight (SINE_DFREQ)")
+            weight_pass(dq, q, ("qkv" if cfg.groups > 1 else "layer") + "_bwd_freq" + ("_bf16" if cfg.flags & 1 else ""))
             dbp = torch.zeros_like(bparams)
             dbp[:, :cfg.G] = q.mul_(w).view(cfg.groups, cfg.I, cfg.G, cfg.O).sum((1, 3))
         if need_b and has_bias:
-            db = dy.view(M, cfg.groups, cfg.O).sum(0)
+            if pd is not None:
+                db = dy[:, pd.prepend_rows:, :].sum((0, 1)).view(1, cfg.O)
+            else:
+                db = dy.view(M, cfg.groups, cfg.O).sum(0)
     return (dx if need_x else None), (du if need_u else None), dw, dbp, db
 
 
@@ -326,8 +346,11 @@ def patchify(images: torch.Tensor, n_patches: int) -> torch.Tensor:
 class _PatchEmbedFn(torch.autograd.Function):
     """images[B, C, H, W] -> tokens[B, P + 1, O] = [cls + pos[0]; layer(patch(b, p)) + pos[1 + p]] in ONE launch (SURVEY.md
     section 8(f)2): the kernel gathers its rows from the NCHW images (no [B, P, I] staging tensor), adds the position
-    embedding in its epilogue and writes the class-token rows.  Backward: the layer's weight gradient runs on a TRANSIENT
-    patch matrix rebuilt from the saved images (one strided copy, freed right after); d cls = sum_b dy[b, 0]."""
+    embedding in its epilogue and writes the class-token rows; with KANVIT_FLAG_BF16_MFMA in cfg.flags (bf16 autocast) the
+    bf16 register-form forward does the same.  Backward: the layer's weight gradient (and SineKAN's frequency pass) gathers
+    its x rows from the saved images and its dY rows from the token-sequence gradient (kanvit_patch_embed_bwd_weight) -- no
+    transient patch matrix, no copy of dY without the class-token rows; layers the gathering kernels do not cover
+    (kanvit_patch_embed_bwd_weight_ok) rebuild a transient patch matrix.  d cls = sum_b dy[b, 0]."""
 
     @staticmethod
     @_fwd_f32
@@ -344,9 +367,14 @@ class _PatchEmbedFn(torch.autograd.Function):
         bp = None if bparams is None else bparams.contiguous()
         bs = None if bias is None else bias.contiguous()
         cl, po = cls.contiguous(), pos.contiguous()
-        with torch.cuda.device(images.device), _timed("layer_fwd", *_layer_cost(cfg, B * P, "fwd")):
-            check(_lib.lib().kanvit_patch_embed_fwd(C.byref(d), C.byref(pd), _ptr(images), _ptr(w), _ptr(bp), _ptr(bs), _ptr(cl),
-                                                     _ptr(po), _ptr(y), _stream()), "kanvit_patch_embed_fwd")
+        bf = bool(cfg.flags & _lib.FLAG_BF16_MFMA)
+        with torch.cuda.device(images.device):
+            nbytes = int(_lib.lib().kanvit_layer_fwd_workspace(C.byref(d))) if bf else 0
+            ws = _workspace(nbytes, images.device) if nbytes else None
+            with _timed("layer_fwd" + ("_bf16" if bf else ""), *_layer_cost(cfg, B * P, "fwd")):
+                check(_lib.lib().kanvit_patch_embed_fwd_ws(C.byref(d), C.byref(pd), _ptr(images), _ptr(w), _ptr(bp), _ptr(bs), _ptr(cl),
+                                                            _ptr(po), _ptr(y), _ptr(ws), C.c_size_t(nbytes), _stream()),
+                      "kanvit_patch_embed_fwd")
         ctx.cfg, ctx.n_patches = cfg, n_patches
         ctx.has_bp, ctx.has_bias = bparams is not None, bias is not None
         ctx.save_for_backward(images, w, bp)
@@ -357,18 +385,32 @@ class _PatchEmbedFn(torch.autograd.Function):
     def backward(ctx, dy):
         images, w, bparams = ctx.saved_tensors
         cfg, P = ctx.cfg, ctx.n_patches ** 2
-        dy = dy.float()
+        dy = dy.float().contiguous()
+        B, Cc, H, W = images.shape
         dcls = dy[:, 0, :].sum(0) if ctx.needs_input_grad[4] else None
-        x = patchify(images, ctx.n_patches).reshape(-1, cfg.I)                 # transient
-        dyt = dy[:, 1:, :].reshape(-1, cfg.O)                                  # transient (contiguous patch-token rows)
         needs = (False, False, ctx.needs_input_grad[1], ctx.needs_input_grad[2] and ctx.has_bp, ctx.needs_input_grad[3] and ctx.has_bias)
-        _, _, dw, dbp, db = _kan_backward(cfg, x, None, w, bparams, dyt, needs, False, ctx.has_bias)
+        pd = _lib.PatchDesc(Cc, H, W, ctx.n_patches, 1, 0)
+        d = _desc(cfg, B * P, cfg.I, cfg.I, cfg.O, 0 if bparams is None else bparams.shape[1])
+        with torch.cuda.device(images.device):
+            gather = bool(_lib.lib().kanvit_patch_embed_bwd_weight_ok(C.byref(d), C.byref(pd))) and not _lib.py_switches()["no_patch_bw"]
+        if cfg.family == SINE and _lib.py_switches()["no_dfreq_w"]:
+            gather = False          # d loss / d freq through the input-gradient kernel needs the patch matrix
+        if gather:
+            _, _, dw, dbp, db = _kan_backward(cfg, images, None, w, bparams, dy, needs, False, ctx.has_bias, patch=(pd, B * P))
+        else:
+            x = patchify(images, ctx.n_patches).reshape(-1, cfg.I)                 # transient
+            dyt = dy[:, 1:, :].reshape(-1, cfg.O)                                  # transient (contiguous patch-token rows)
+            _, _, dw, dbp, db = _kan_backward(cfg, x, None, w, bparams, dyt, needs, False, ctx.has_bias)
         return None, dw, dbp, db, dcls, None, None, None
 
 
 def patch_embed(images, w, cfg: LayerCfg, bparams, bias, cls, pos, n_patches: int) -> torch.Tensor:
     """Fused patch embedding (see _PatchEmbedFn); w is the packed weight [1, K, O], cls [O], pos [P + 1, O].  Raises
-    KanvitError for shapes the fused kernel does not cover (the caller falls back to patchify + kan_layer)."""
+    KanvitError for shapes the fused kernel does not cover (the caller falls back to patchify + kan_layer).  Under bf16
+    autocast the contraction runs on the bf16 matrix cores (KANVIT_FLAG_BF16_MFMA), as kan_layer() does."""
+    if _autocast_flags() and not (cfg.flags & _lib.FLAG_BF16_MFMA):
+        from dataclasses import replace
+        cfg = replace(cfg, flags=cfg.flags | _lib.FLAG_BF16_MFMA)
     return _PatchEmbedFn.apply(images, w, bparams, bias, cls, pos, cfg, n_patches)
 
 

@@ -131,7 +131,7 @@ class VisionTransformer(nn.Module):
             self.blocks = nn.ModuleList([TransformerBlock(d_hidden, n_heads, feedforward_dim=4 * d_hidden,
                                                           attn_type=self.block_types[l]) for l in range(n_blocks)])
         self.mlp_head = nn.Sequential(nn.LayerNorm(d_hidden), nn.Linear(d_hidden, out_d))
-        self._fused_embed = None       # None = not tried yet, True / False = the fused patch-embedding kernel covers this model
+        self._fused_embed = None       # None = not tried yet, else {bf16 autocast?: the fused patch-embedding kernel covers this model}
 
     def patchify(self, images, n_patches):
         """(B, C, H, W) -> (B, n_patches^2, C*ph*pw): patches row-major, each flattened in (C, ph, pw)
@@ -154,16 +154,21 @@ class VisionTransformer(nn.Module):
     def _embed_fused(self, images):
         """patchify + patch-embedding KAN layer + class token + position embedding in ONE kernel launch (SURVEY.md section
         8(f)2; kanvit.ops.patch_embed), or None when the fused kernel does not cover this layer / geometry (then the
-        three-step path below runs: same arithmetic).  The exact fp32 path only: under bf16 autocast the layer runs on
-        the bf16 matrix cores, whose kernels have no gather."""
+        three-step path below runs: same arithmetic).  Under bf16 autocast the same launch runs on the bf16 matrix cores."""
         lm = self.linear_mapper
-        if self._fused_embed is False or isinstance(lm, nn.Linear) or not hasattr(lm, "kan_pack") or hasattr(lm, "kan_u"):
+        if isinstance(lm, nn.Linear) or not hasattr(lm, "kan_pack") or hasattr(lm, "kan_u"):
+            return None
+        # the cached per-model decision is per arithmetic mode: the fp32 and the bf16 kernels tile the patch width differently
+        mode = bool(torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        if self._fused_embed is None:
+            self._fused_embed = {}
+        if self._fused_embed.get(mode) is False:
             return None
         # per-call conditions (they depend on the INPUT, so they never touch the cached per-model decision): the kernel wants
         # contiguous-able fp32 NCHW on the GPU at a 16-byte aligned address, and it produces no gradient for the images --
         # a caller that differentiates w.r.t. the input (saliency, adversarial examples) takes the three-step path below
         if (not images.is_cuda or images.dim() != 4 or images.dtype != torch.float32 or images.requires_grad
-                or torch.is_autocast_enabled("cuda") or (images.is_contiguous() and images.data_ptr() % 16)):
+                or (images.is_contiguous() and images.data_ptr() % 16)):
             return None
         cfg = lm.kan_cfg()
         w, bp, bias = lm.kan_pack()
@@ -172,11 +177,11 @@ class VisionTransformer(nn.Module):
                                   None if bias is None else bias.reshape(1, -1), self.v_class.reshape(-1),
                                   self.pos_embeddings[: self.n_patches ** 2 + 1], self.n_patches)
         except ops.KanvitError:
-            if self._fused_embed is None:                  # layer / geometry not covered: decided once, at the first forward
-                self._fused_embed = False
+            if mode not in self._fused_embed:              # layer / geometry not covered: decided once, at the first forward of a mode
+                self._fused_embed[mode] = False
                 return None
             raise
-        self._fused_embed = True
+        self._fused_embed[mode] = True
         return out
 
     def forward(self, images):

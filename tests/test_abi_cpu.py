@@ -79,7 +79,7 @@ def test_descriptor_layout_and_errors(lib):
     from kanvit import _lib
     assert ctypes.sizeof(_lib.LayerDesc) == 10 * 4 + 5 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.AttnDesc) == 8 * 4 + 12 * 8
-    assert lib.kanvit_abi_version() == 6
+    assert lib.kanvit_abi_version() == 7
     d = _lib.LayerDesc(family=99, groups=1, x_group_mod=1, I=4, O=3, G=1, M=6, ldx=4, ldy=3)
     rc = lib.kanvit_layer_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
     assert rc == -22 and b"family" in lib.kanvit_last_error()
