@@ -234,6 +234,28 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
                     const float* o, const float* lse, const float* d_o,
                     float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- general attention core: q_len != k_len and an attend-mask (ABI >= 7) -----------------------------------------
+ * The rest of FlashAttentionFunction's domain (utils.py:134-295): independent query / key lengths (cross-attention through
+ * FlashAttention(context=...), attention.py:59-109; utils.py:150-160), a boolean mask broadcastable to [b, h, q_len, k_len]
+ * (a [b, k_len] key-padding mask is [b, 1, 1, k_len], utils.py:156-157; nonzero = attend).  `causal` (key j > query i dead)
+ * needs k_len <= q_len: with k_len > q_len utils.py:169 shifts the diagonal so that the first k_len - q_len queries see no
+ * key and the reference's answer depends on its bucket sizes -- KANVIT_EINVAL here.  d as for kanvit_attn_fwd with
+ * d->N = q_len (q, o, do, dq: [B][H][q_len][D] through the q / o strides; k, v, dk, dv: [B][H][Nk][D] through the k / v
+ * strides; lse [B][H][q_len]).  Exact fp32 (KANVIT_FLAG_BF16_MFMA is refused).  A query whose keys are all dead gets o = 0,
+ * lse = -FLT_MAX, zero gradients.  The swept operand of a head must fit the LDS: q_len, k_len <= 224 (256 for D <= 32). */
+typedef struct kanvit_attn_ext {
+    int32_t Nk;              /* key / value length */
+    int32_t reserved;
+    const void* mask;        /* NULL, or bytes (torch.bool): element (b, h, i, j) at mask[b*sb + h*sh + i*sq + j*sk] */
+    int64_t mask_stride_b, mask_stride_h, mask_stride_q, mask_stride_k;      /* in bytes = elements; 0 broadcasts */
+} kanvit_attn_ext;
+int kanvit_attn_x_fwd(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const float* q, const float* k, const float* v,
+                      float* o, float* lse, void* stream);
+size_t kanvit_attn_x_bwd_workspace(const kanvit_attn_desc* d, const kanvit_attn_ext* e);
+int kanvit_attn_x_bwd(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const float* q, const float* k, const float* v,
+                      const float* o, const float* lse, const float* d_o, float* dq, float* dk, float* dv, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- fused feed-forward for the small geometries ---------------------------------------------
  * y = relu(x W1^T + b1) W2^T + b2, the TransformerBlock's nn.Sequential(Linear, ReLU(inplace), Linear) (model.py:25-29,36),
  * x[M][D], W1[F][D], b1[F], W2[D][F], b2[D] in nn.Linear's own layouts; fp32 products and sums.  Forward: one launch;

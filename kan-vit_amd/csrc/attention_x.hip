@@ -1,0 +1,497 @@
+// General attention core: independent query / key lengths and a boolean attend-mask (exact fp32).
+//
+// FlashAttentionFunction (utils.py:134-295) tiles over independent q / k lengths (utils.py:150-160, cross-attention through
+// FlashAttention(context=...), attention.py:59-109) and takes a mask broadcastable to [b, h, q_len, k_len] (a [b, k_len]
+// key-padding mask is viewed as [b, 1, 1, k_len], utils.py:156-157).  `causal` (key j > query i is dead, utils.py:178-190) is taken
+// for k_len <= q_len only: with k_len > q_len the reference shifts the diagonal the wrong way (utils.py:169 SUBTRACTS qk_len_diff:
+// query i sees keys j <= i - (k_len - q_len)), the first k_len - q_len queries have no visible key and its answer for them depends
+// on the bucket sizes -- refused here (KANVIT_EINVAL) instead of imitated.  The ViT path never uses either (attention.hip's kernels: one length, no
+// mask); these kernels cover the rest of the function's domain with the same tile orientation as attention.hip's first form:
+//   forward       work-group = one (batch, head): K, V images [NKP][KS] in LDS, a wave owns a 32-query tile,
+//                 S^T = K.Q^T with the key index in the accumulator register index -> exact softmax in registers (no online
+//                 rescale: all <= 8 key tiles of a strip are live) -> O^T = V^T.P^T from registers
+//   backward      rowsum(dO*O) (attn_x_delta_kernel), then a key-stationary kernel (Q, dO images in LDS; dK^T, dV^T in
+//                 accumulators) and a query-stationary one (K, V images in LDS; dQ^T in accumulators): no atomics, bitwise
+//                 reproducible
+// A position is dead when key >= k_len, or causal and key > query, or the mask says so.  A query whose keys are ALL
+// dead gets o = 0, lse = -FLT_MAX and zero gradients (the reference's clamp(min=EPSILON) row sum gives the same o = 0 and
+// lse = log(1e-10) - FLT_MAX for a fully MASKED row).
+// Limits (host-checked): D even and <= 64; the swept operand of a head must fit the LDS: k_len (forward, dQ) and q_len (dK, dV)
+// <= 224 at D > 32, <= 256 at D <= 32.
+#include "kanvit_common.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr int XTHR = 256;
+constexpr float LOG2E_X = 1.4426950408889634f;
+
+struct AttnXArgs {
+    const float* q;
+    const float* k;
+    const float* v;
+    const float* o;
+    const float* lse_in;
+    const float* d_o;
+    const float* delta_in;
+    const unsigned char* mask;      // nonzero = attend; element (b, h, i, j) at mask[b*msb + h*msh + i*msq + j*msk] (0 strides broadcast)
+    float* out;
+    float* lse;
+    float* dq;
+    float* dk;
+    float* dv;
+    float* delta;
+    long long msb, msh, msq, msk;
+    long long qsb, qsh, qsn, ksb, ksh, ksn, vsb, vsh, vsn, osb, osh, osn;
+    int B, H, Nq, Nk, D, causal, nqt, nkt;
+    float scale;
+};
+
+__device__ __forceinline__ bool x_dead(const AttnXArgs& a, const unsigned char* mrow_base, int qrow, int key) {
+    if (key >= a.Nk || (a.causal && key > qrow)) return true;
+    if (mrow_base) {
+        const int qi = qrow < a.Nq ? qrow : a.Nq - 1;
+        return mrow_base[(long long)qi * a.msq + (long long)key * a.msk] == 0;
+    }
+    return false;
+}
+
+// dst[rows][KS] <- src rows row0.. (row stride stride_n), zero beyond n_valid rows and D columns
+template <int DT>
+__device__ __forceinline__ void x_load_tile(float* __restrict__ dst, const float* __restrict__ src, long long stride_n, int row0,
+                                            int rows, int n_valid, int D, int tid, int nthr) {
+    constexpr int W = 32 * DT, KS = W + 1;
+    for (int idx = tid; idx < rows * W; idx += nthr) {
+        const int r = idx / W, c = idx - r * W;
+        const int n = row0 + r;
+        dst[r * KS + c] = (n < n_valid && c < D) ? src[(long long)n * stride_n + c] : 0.0f;
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ void x_store_tile(float* __restrict__ dstg, long long stride_n, int row0, int n_valid, int D,
+                                             const float* __restrict__ T, int lane) {
+    constexpr int KS = 32 * DT + 1;
+    for (int idx = lane; idx < 32 * D; idx += 64) {
+        const int r = idx / D, c = idx - r * D;
+        const int n = row0 + r;
+        if (n < n_valid) dstg[(long long)n * stride_n + c] = T[r * KS + c];
+    }
+}
+
+template <int DT, int NKT>
+__global__ __launch_bounds__(XTHR) void attn_x_fwd_kernel(const AttnXArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 32 * DT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int D = a.D, nkt = a.nkt, NKP = nkt * 32;
+    float* K_s = smem;
+    float* V_s = K_s + NKP * KS;
+    float* Q_w = V_s + NKP * KS + wave * 32 * KS;
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    float* ob = a.out + bi * a.osb + hi * a.osh;
+    const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
+
+    x_load_tile<DT>(K_s, kb, a.ksn, 0, NKP, a.Nk, D, tid, XTHR);
+    x_load_tile<DT>(V_s, vb, a.vsn, 0, NKP, a.Nk, D, tid, XTHR);
+
+    const float sc2 = a.scale * LOG2E_X;
+    const int niter = (a.nqt + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int qt = it * 4 + wave;            // tiles past nqt run on zero rows and store nothing
+        x_load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+        __syncthreads();
+        float qf[16 * DT];
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) qf[s] = Q_w[l31 * KS + 2 * s + hf];
+
+        f32x16 sacc[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
+            if (j < nkt) {
+                const float* kp = K_s + (j * 32 + l31) * KS + hf;
+#pragma unroll
+                for (int s = 0; s < 16 * DT; ++s) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc[j], 0, 0, 0);
+            }
+        }
+        const int qrow = qt * 32 + l31;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = j * 32 + kv_acc_row(r, hf);
+                    const float sv = x_dead(a, mb, qrow, key) ? -INFINITY : sacc[j][r];
+                    sacc[j][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mxs = (mx == -INFINITY) ? 0.0f : mx * sc2;
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(sacc[j][r] * sc2 - mxs);
+                    sacc[j][r] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;          // every key dead: o = 0
+
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = sacc[j][r] * inv;
+                    const float* vp = V_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], pv, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = oacc[dt][r];
+        __syncthreads();
+        if (qt < a.nqt) {
+            x_store_tile<DT>(ob, a.osn, qt * 32, a.Nq, D, Q_w, lane);
+            if (hf == 0 && qrow < a.Nq && a.lse) a.lse[(long long)bh * a.Nq + qrow] = sum > 0.0f ? mx * a.scale + logf(sum) : -FLT_MAX;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_x_delta_kernel(const AttnXArgs a) {
+    const int sub = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long rows = (long long)a.B * a.H * a.Nq;
+    float s = 0.0f;
+    if (row < rows) {
+        const int n = (int)(row % a.Nq);
+        const long long bh = row / a.Nq;
+        const int hi = (int)(bh % a.H);
+        const long long bi = bh / a.H;
+        const float* op = a.o + bi * a.osb + hi * a.osh + (long long)n * a.osn;
+        const float* dp = a.d_o + bi * a.osb + hi * a.osh + (long long)n * a.osn;
+        for (int c = sub; c < a.D; c += 16) s += op[c] * dp[c];
+    }
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    if (row < rows && sub == 0) a.delta[row] = s;
+}
+
+// dK, dV: key-stationary (a wave owns a 32-key tile and sweeps the query tiles; utils.py:262-291)
+template <int DT>
+__global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 32 * DT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int D = a.D, NQP = a.nqt * 32;
+    float* Q_s = smem;
+    float* dO_s = Q_s + NQP * KS;
+    float* lse_s = dO_s + NQP * KS;
+    float* dl_s = lse_s + NQP;
+    float* T_w = dl_s + NQP + wave * 32 * KS;
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    float* dkb = a.dk + bi * a.ksb + hi * a.ksh;
+    float* dvb = a.dv + bi * a.vsb + hi * a.vsh;
+    const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
+
+    x_load_tile<DT>(Q_s, qb, a.qsn, 0, NQP, a.Nq, D, tid, XTHR);
+    x_load_tile<DT>(dO_s, dob, a.osn, 0, NQP, a.Nq, D, tid, XTHR);
+    for (int n = tid; n < NQP; n += XTHR) {
+        lse_s[n] = (n < a.Nq) ? a.lse_in[(long long)bh * a.Nq + n] * LOG2E_X : INFINITY;
+        dl_s[n] = (n < a.Nq) ? a.delta_in[(long long)bh * a.Nq + n] : 0.0f;
+    }
+    const float sc2 = a.scale * LOG2E_X;
+    const int niter = (a.nkt + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int jt = it * 4 + wave;
+        const int key = jt * 32 + l31;
+        float kf[16 * DT], vf[16 * DT];
+        x_load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
+        __syncthreads();
+        x_load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
+
+        f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[dt][r] = 0.0f;
+                dvacc[dt][r] = 0.0f;
+            }
+        for (int qt = 0; qt < a.nqt; ++qt) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            const float* qp = Q_s + (qt * 32 + l31) * KS + hf;
+            const float* dp = dO_s + (qt * 32 + l31) * KS + hf;
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * s], kf[s], sacc, 0, 0, 0);      // S[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[2 * s], vf[s], pacc, 0, 0, 0);      // dP[q][key]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = qt * 32 + kv_acc_row(r, hf);
+                float p = exp2f(sacc[r] * sc2 - lse_s[qrow]);
+                if (jt >= a.nkt || qrow >= a.Nq || x_dead(a, mb, qrow, key)) p = 0.0f;          // select, never multiply: exp2 may be inf on a dead row
+                sacc[r] = p;
+                pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
+                if (p == 0.0f) pacc[r] = 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (qt * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dO_s[row + dt * 32], sacc[r], dvacc[dt], 0, 0, 0);
+                    dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Q_s[row + dt * 32], pacc[r], dkacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dkacc[dt][r];
+        __syncthreads();
+        if (jt < a.nkt) x_store_tile<DT>(dkb, a.ksn, jt * 32, a.Nk, D, T_w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dvacc[dt][r];
+        __syncthreads();
+        if (jt < a.nkt) x_store_tile<DT>(dvb, a.vsn, jt * 32, a.Nk, D, T_w, lane);
+        __syncthreads();
+    }
+}
+
+// dQ: query-stationary mirror of the forward kernel
+template <int DT>
+__global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 32 * DT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
+    const int D = a.D, nkt = a.nkt, NKP = nkt * 32;
+    float* K_s = smem;
+    float* V_s = K_s + NKP * KS;
+    float* T_w = V_s + NKP * KS + wave * 32 * KS;
+
+    const float* qb = a.q + bi * a.qsb + hi * a.qsh;
+    const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+    const float* vb = a.v + bi * a.vsb + hi * a.vsh;
+    const float* dob = a.d_o + bi * a.osb + hi * a.osh;
+    float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
+    const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
+
+    x_load_tile<DT>(K_s, kb, a.ksn, 0, NKP, a.Nk, D, tid, XTHR);
+    x_load_tile<DT>(V_s, vb, a.vsn, 0, NKP, a.Nk, D, tid, XTHR);
+    const float sc2 = a.scale * LOG2E_X;
+    const int niter = (a.nqt + 3) / 4;
+    for (int it = 0; it < niter; ++it) {
+        const int qt = it * 4 + wave;
+        const int qrow = qt * 32 + l31;
+        const bool q_ok = (qt < a.nqt) && (qrow < a.Nq);
+        float qf[16 * DT], dof[16 * DT];
+        x_load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
+        __syncthreads();
+        x_load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
+        const float lse2 = q_ok ? a.lse_in[(long long)bh * a.Nq + qrow] * LOG2E_X : INFINITY;
+        const float dl = q_ok ? a.delta_in[(long long)bh * a.Nq + qrow] : 0.0f;
+
+        f32x16 dqacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+        for (int j = 0; j < nkt; ++j) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = 0.0f;
+                pacc[r] = 0.0f;
+            }
+            const float* kp = K_s + (j * 32 + l31) * KS + hf;
+            const float* vp = V_s + (j * 32 + l31) * KS + hf;
+#pragma unroll
+            for (int s = 0; s < 16 * DT; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc, 0, 0, 0);      // S^T[key][q]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], dof[s], pacc, 0, 0, 0);     // dP^T[key][q]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j * 32 + kv_acc_row(r, hf);
+                const float p = exp2f(sacc[r] * sc2 - lse2);
+                const bool dead = !q_ok || x_dead(a, mb, qrow, key);
+                pacc[r] = dead ? 0.0f : p * a.scale * (pacc[r] - dl);                             // dS^T
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* kr = K_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[dt * 32], pacc[r], dqacc[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dqacc[dt][r];
+        __syncthreads();
+        if (qt < a.nqt) x_store_tile<DT>(dqb, a.qsn, qt * 32, a.Nq, D, T_w, lane);
+        __syncthreads();
+    }
+}
+
+int x_check(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const char* who) {
+    if (!d || !e) return kv_fail(KANVIT_EINVAL, "%s: null descriptor", who);
+    if (d->B < 0 || d->H < 1 || d->N < 1 || e->Nk < 1 || d->D < 1) return kv_fail(KANVIT_EINVAL, "%s: bad sizes", who);
+    if (d->D > KANVIT_ATTN_MAX_D || (d->D & 1)) return kv_fail(KANVIT_EINVAL, "%s: D=%d must be even and <= %d", who, d->D, KANVIT_ATTN_MAX_D);
+    if ((long long)d->B * d->H > 0x7fffffffLL) return kv_fail(KANVIT_EINVAL, "%s: B*H too large", who);
+    if (d->causal && e->Nk > d->N)
+        return kv_fail(KANVIT_EINVAL, "%s: causal with k_len=%d > q_len=%d is ill-defined in the reference (utils.py:169,183: the first k_len - q_len queries see no key)", who, e->Nk, d->N);
+    if (d->flags & KANVIT_FLAG_BF16_MFMA) return kv_fail(KANVIT_EINVAL, "%s: the general attention kernels are exact fp32 (no KANVIT_FLAG_BF16_MFMA)", who);
+    const int ks = (d->D <= 32 ? 32 : 64) + 1;
+    const int nmax = d->N > e->Nk ? d->N : e->Nk, np = (nmax + 31) / 32 * 32;
+    const size_t lds = sizeof(float) * ((size_t)2 * np * ks + 2 * (size_t)np + (size_t)4 * 32 * ks);
+    if (np > 256 || lds > 160 * 1024)
+        return kv_fail(KANVIT_EINVAL, "%s: q_len=%d, k_len=%d with D=%d: the swept operand of a head must fit a CU's LDS (%zu bytes > 160 KiB)", who,
+                       d->N, e->Nk, d->D, lds);
+    return 0;
+}
+
+AttnXArgs x_args(const kanvit_attn_desc* d, const kanvit_attn_ext* e) {
+    AttnXArgs a{};
+    a.B = d->B; a.H = d->H; a.Nq = d->N; a.Nk = e->Nk; a.D = d->D; a.causal = d->causal; a.scale = d->scale;
+    a.nqt = (d->N + 31) / 32;
+    a.nkt = (e->Nk + 31) / 32;
+    a.qsb = d->q_stride_b; a.qsh = d->q_stride_h; a.qsn = d->q_stride_n;
+    a.ksb = d->k_stride_b; a.ksh = d->k_stride_h; a.ksn = d->k_stride_n;
+    a.vsb = d->v_stride_b; a.vsh = d->v_stride_h; a.vsn = d->v_stride_n;
+    a.osb = d->o_stride_b; a.osh = d->o_stride_h; a.osn = d->o_stride_n;
+    a.mask = (const unsigned char*)e->mask;
+    a.msb = e->mask_stride_b; a.msh = e->mask_stride_h; a.msq = e->mask_stride_q; a.msk = e->mask_stride_k;
+    return a;
+}
+
+template <int DT>
+int x_launch_fwd(const AttnXArgs& a, hipStream_t st) {
+    constexpr int KS = 32 * DT + 1;
+    const size_t lds = sizeof(float) * ((size_t)2 * a.nkt * 32 * KS + (size_t)4 * 32 * KS);
+    const dim3 grid((unsigned)(a.B * a.H));
+    if (a.nkt <= 2) {
+        KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT, 2>));
+        hipLaunchKernelGGL((attn_x_fwd_kernel<DT, 2>), grid, dim3(XTHR), lds, st, a);
+    } else if (a.nkt <= 4) {
+        KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT, 4>));
+        hipLaunchKernelGGL((attn_x_fwd_kernel<DT, 4>), grid, dim3(XTHR), lds, st, a);
+    } else {
+        KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT, 8>));
+        hipLaunchKernelGGL((attn_x_fwd_kernel<DT, 8>), grid, dim3(XTHR), lds, st, a);
+    }
+    KV_LAUNCH_CHECK("attn_x_fwd_kernel");
+    return 0;
+}
+
+template <int DT>
+int x_launch_bwd(const AttnXArgs& a, hipStream_t st) {
+    constexpr int KS = 32 * DT + 1;
+    const size_t lds_kv = sizeof(float) * ((size_t)2 * a.nqt * 32 * KS + 2 * (size_t)a.nqt * 32 + (size_t)4 * 32 * KS);
+    const size_t lds_q = sizeof(float) * ((size_t)2 * a.nkt * 32 * KS + (size_t)4 * 32 * KS);
+    const dim3 grid((unsigned)(a.B * a.H));
+    KV_ALLOW_LDS(160 * 1024, (attn_x_bwd_kv_kernel<DT>));
+    KV_ALLOW_LDS(160 * 1024, (attn_x_bwd_q_kernel<DT>));
+    hipLaunchKernelGGL((attn_x_bwd_kv_kernel<DT>), grid, dim3(XTHR), lds_kv, st, a);
+    KV_LAUNCH_CHECK("attn_x_bwd_kv_kernel");
+    hipLaunchKernelGGL((attn_x_bwd_q_kernel<DT>), grid, dim3(XTHR), lds_q, st, a);
+    KV_LAUNCH_CHECK("attn_x_bwd_q_kernel");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kanvit_attn_x_fwd(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const float* q, const float* k, const float* v, float* o,
+                      float* lse, void* stream) {
+    if (int rc = x_check(d, e, "kanvit_attn_x_fwd")) return rc;
+    if (!q || !k || !v || !o) return kv_fail(KANVIT_EINVAL, "kanvit_attn_x_fwd: null q/k/v/o");
+    if (d->B == 0) return 0;
+    AttnXArgs a = x_args(d, e);
+    a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
+    hipStream_t st = (hipStream_t)stream;
+    return d->D <= 32 ? x_launch_fwd<1>(a, st) : x_launch_fwd<2>(a, st);
+}
+
+size_t kanvit_attn_x_bwd_workspace(const kanvit_attn_desc* d, const kanvit_attn_ext* e) {
+    if (!d || !e || d->B < 0 || d->H < 1 || d->N < 1) return 0;
+    return (sizeof(float) * (size_t)d->B * d->H * d->N + 15) / 16 * 16;         // rowsum(dO*O), "D" of utils.py:286
+}
+
+int kanvit_attn_x_bwd(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const float* q, const float* k, const float* v, const float* o,
+                      const float* lse, const float* d_o, float* dq, float* dk, float* dv, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (int rc = x_check(d, e, "kanvit_attn_x_bwd")) return rc;
+    if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv) return kv_fail(KANVIT_EINVAL, "kanvit_attn_x_bwd: null argument");
+    if (d->B == 0) return 0;
+    const size_t need = kanvit_attn_x_bwd_workspace(d, e);
+    if (!workspace || workspace_bytes < need) return kv_fail(KANVIT_ENOMEM, "kanvit_attn_x_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+    AttnXArgs a = x_args(d, e);
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse_in = lse; a.d_o = d_o;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.delta = (float*)workspace; a.delta_in = (const float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)d->B * d->H * d->N;
+    hipLaunchKernelGGL(attn_x_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
+    KV_LAUNCH_CHECK("attn_x_delta_kernel");
+    return d->D <= 32 ? x_launch_bwd<1>(a, st) : x_launch_bwd<2>(a, st);
+}
+
+}  // extern "C"

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     // and slab numbers, tile columns, the slab's base pointers -- in scalar registers instead of one vector register each.
     // Applied where the register file is the limit (B-spline / FastKAN, the G = 28 windows: it removes their scratch spills,
     // FastKAN q|k|v 968 -> 945 us); the Chebyshev / linear / narrow-sine instantiations measured 7 % SLOWER with it (373 -> 401 us).
-    constexpr bool SCALAR_WAVE = FAM == KV_BSPLINE || FAM == KV_RBF || GP >= 28;
+    constexpr bool SCALAR_WAVE = FAM == KV_BSPLINE || FAM == KV_RBF || GP >= 28 || PG;      // (PG: the row walker lives on the scalar unit only under wave-uniform control flow)
     const int lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int wave = SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     // wave unit u = (basis group, column-tile set, feature block), feature block fastest: the 4 waves of a work-group are
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     // rows past the slab take the slab's first row (their dY is zeroed when the block leaves the ring)
     PatchWalk walk;
     int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0;
+    const int pg_hm = -hf;                       // all ones in the upper lane half
     if constexpr (PG) {
         walk.init(a, __builtin_amdgcn_readfirstlane((int)ms));
         pg_x0 = walk.xoff;
@@ -146,8 +147,10 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
             }
 #pragma unroll
             for (int t = 0; t < NTOK; ++t) {
+                // this lane's row is k0 (lower lane half) or k1 (upper): base + (difference & lane mask) -- written as a select, the
+                // pair becomes a dynamically indexed read of sx[] and a chain of seven v_cndmask per value
                 const int k0 = BF ? t : 2 * t, k1 = BF ? 8 + t : 2 * t + 1;
-                const int xo = hf ? sx[k1] : sx[k0], dyr = hf ? sdy[k1] : sdy[k0];
+                const int xo = sx[k0] + ((sx[k1] - sx[k0]) & pg_hm), dyr = sdy[k0] + ((sdy[k1] - sdy[k0]) & pg_hm);
                 rx[q][t] = a.x[xo + pg_f];
 #pragma unroll
                 for (int i = 0; i < NOT; ++i) rdy[q][t][i] = a.dy[dyr + dyo[i]];
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
         auto tok_of = [&](int blk, int t) -> int { return 4 * (blk * UB + t) + tq; };
         PatchWalk walk;                       // patch gather: see kan_bwd_weight_reg_kernel
         int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0;
+        const int pg_m1 = -(int)(tq == 1), pg_m2 = -(int)(tq == 2), pg_m3 = -(int)(tq == 3);
         if constexpr (PG) {
             static_assert(!PG || UB == 1, "one step of four rows per block");
             walk.init(a, __builtin_amdgcn_readfirstlane((int)ms));
@@ -371,9 +375,10 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
                     sdy[k] = in ? walk.dyoff : pg_dy0;
                     walk.step();
                 }
-                const bool t1 = tq & 1, t2 = tq & 2;          // lane group tq takes row tq of the block
-                const int xo = t2 ? (t1 ? sx[3] : sx[2]) : (t1 ? sx[1] : sx[0]);
-                const int dyr = t2 ? (t1 ? sdy[3] : sdy[2]) : (t1 ? sdy[1] : sdy[0]);
+                // lane group tq takes row tq of the block: base + the masked differences (a select tree becomes a dynamically
+                // indexed read of sx[]: a v_cndmask chain per value)
+                const int xo = sx[0] + (((sx[1] - sx[0]) & pg_m1) | ((sx[2] - sx[0]) & pg_m2) | ((sx[3] - sx[0]) & pg_m3));
+                const int dyr = sdy[0] + (((sdy[1] - sdy[0]) & pg_m1) | ((sdy[2] - sdy[0]) & pg_m2) | ((sdy[3] - sdy[0]) & pg_m3));
                 rx[q][0] = a.x[xo + pg_f];
 #pragma unroll
                 for (int i = 0; i < NC; ++i) rdy[q][0][i] = a.dy[dyr + dyo[i]];

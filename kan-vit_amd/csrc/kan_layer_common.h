@@ -119,18 +119,15 @@ struct PatchWalk {
         line_wrap = ph * a.pg_W - n * pw;                       // last patch of a patch row -> first patch of the next one
         img_wrap = (a.pg_C * a.pg_H - n * ph) * a.pg_W;         // last patch of an image -> first patch of the next image
     }
-    __device__ __forceinline__ void step() {
-        xoff += pw;
-        dyoff += ldy;
-        if (++px == n) {
-            px = 0;
-            xoff += line_wrap;
-            if (++py == n) {
-                py = 0;
-                xoff += img_wrap;
-                dyoff += pre_ldy;
-            }
-        }
+    __device__ __forceinline__ void step() {      // branch-free: compares and selects on wave-uniform values (s_cmp / s_cselect)
+        ++px;
+        const bool w1 = px == n;                  // past the last patch of a patch row
+        px = w1 ? 0 : px;
+        py += w1 ? 1 : 0;
+        const bool w2 = py == n;                  // past the last patch row of an image
+        py = w2 ? 0 : py;
+        xoff += pw + (w1 ? line_wrap : 0) + (w2 ? img_wrap : 0);
+        dyoff += ldy + (w2 ? pre_ldy : 0);
     }
 };
 

@@ -45,6 +45,11 @@ class AttnDesc(C.Structure):
                 ("o_stride_b", C.c_int64), ("o_stride_h", C.c_int64), ("o_stride_n", C.c_int64)]
 
 
+class AttnExt(C.Structure):
+    _fields_ = [("Nk", C.c_int32), ("reserved", C.c_int32), ("mask", C.c_void_p),
+                ("mask_stride_b", C.c_int64), ("mask_stride_h", C.c_int64), ("mask_stride_q", C.c_int64), ("mask_stride_k", C.c_int64)]
+
+
 class PatchDesc(C.Structure):
     _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_patches", C.c_int32), ("prepend_rows", C.c_int32),
                 ("reserved", C.c_int32)]
@@ -88,6 +93,9 @@ SYMBOLS = {
     "kanvit_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
     "kanvit_attn_bwd_workspace": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "kanvit_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "kanvit_attn_x_fwd": (C.c_int, [C.POINTER(AttnDesc), C.POINTER(AttnExt), _P, _P, _P, _P, _P, _P]),
+    "kanvit_attn_x_bwd_workspace": (C.c_size_t, [C.POINTER(AttnDesc), C.POINTER(AttnExt)]),
+    "kanvit_attn_x_bwd": (C.c_int, [C.POINTER(AttnDesc), C.POINTER(AttnExt), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "kanvit_addln_fwd": (C.c_int, [C.c_int64, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "kanvit_addln_fwd_ex": (C.c_int, [C.c_int64, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "kanvit_addln_bwd_ex": (C.c_int, [C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -473,6 +473,52 @@ def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale, flags=0):
                                 _ptr(dv), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_attn_bwd")
 
 
+def _attn_x_desc(q, k, v, o, mask, causal: bool, scale: float):
+    """Descriptor pair of the general attention kernels (kanvit_attn_x_*): q, o [B, H, Nq, D]; k, v [B, H, Nk, D]; mask None or a
+    torch.bool tensor already expanded (views, no copy) to [B, H, Nq, Nk]."""
+    B, H, Nq, D = q.shape
+    Nk = k.shape[2]
+    if tuple(k.shape) != (B, H, Nk, D) or tuple(v.shape) != (B, H, Nk, D) or tuple(o.shape) != (B, H, Nq, D):
+        raise KanvitError(f"attention: q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)}, o {tuple(o.shape)} do not agree")
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        if t.stride(3) != 1:
+            raise KanvitError(f"{n}: innermost dimension must be contiguous")
+    d = AttnDesc(B, H, Nq, D, int(bool(causal)), float(scale), 0, 0,
+                 q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                 v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2))
+    if mask is None:
+        e = _lib.AttnExt(Nk, 0, None, 0, 0, 0, 0)
+    else:
+        if mask.dtype != torch.bool or not mask.is_cuda or tuple(mask.shape) != (B, H, Nq, Nk):
+            raise KanvitError(f"attention mask: need a torch.bool GPU tensor expanded to {(B, H, Nq, Nk)}, got {mask.dtype} {tuple(mask.shape)}")
+        e = _lib.AttnExt(Nk, 0, mask.data_ptr(), mask.stride(0), mask.stride(1), mask.stride(2), mask.stride(3))
+    return d, e
+
+
+def _attn_x_fwd(q, k, v, o, mask, causal, scale):
+    B, H, Nq, D = q.shape
+    lse = torch.empty(B, H, Nq, device=q.device, dtype=torch.float32)
+    d, e = _attn_x_desc(q, k, v, o, mask, causal, scale)
+    Nk = k.shape[2]
+    with torch.cuda.device(q.device), _timed("attn_x_fwd", 4 * B * H * Nq * Nk * D, 4 * 2 * B * H * (Nq + Nk) * D):
+        check(_lib.lib().kanvit_attn_x_fwd(C.byref(d), C.byref(e), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()), "kanvit_attn_x_fwd")
+    return lse
+
+
+def _attn_x_bwd(q, k, v, o, lse, do, dq, dk, dv, mask, causal, scale):
+    d, e = _attn_x_desc(q, k, v, o, mask, causal, scale)
+    if (do.stride() != o.stride()) or dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != v.stride():
+        raise KanvitError("attention backward: gradient layouts must match their forward tensors")
+    L = _lib.lib()
+    nbytes = int(L.kanvit_attn_x_bwd_workspace(C.byref(d), C.byref(e)))
+    ws = torch.empty(max(nbytes // 4, 1), device=q.device, dtype=torch.float32)
+    B, H, Nq, D = q.shape
+    Nk = k.shape[2]
+    with torch.cuda.device(q.device), _timed("attn_x_bwd", 14 * B * H * Nq * Nk * D, 4 * 4 * B * H * (Nq + Nk) * D):
+        check(L.kanvit_attn_x_bwd(C.byref(d), C.byref(e), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(do), _ptr(dq), _ptr(dk),
+                                  _ptr(dv), _ptr(ws), C.c_size_t(nbytes), _stream()), "kanvit_attn_x_bwd")
+
+
 class _AttnPackedFn(torch.autograd.Function):
     """qkv[B, N, 3, H, D] (the layout the grouped q|k|v KAN launch writes) -> o[B, N, H*D]."""
 

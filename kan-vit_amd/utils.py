@@ -25,36 +25,49 @@ def default(val, d):
 
 class FlashAttentionFunction(Function):
     """Same call signature as the reference (utils.py:137): apply(q, k, v, mask, causal,
-    q_bucket_size, k_bucket_size) with q/k/v of shape (b, h, n, d).  The bucket sizes only chose
+    q_bucket_size, k_bucket_size) with q (b, h, q_len, d) and k, v (b, h, k_len, d).  The bucket sizes only chose
     the tiling of the python implementation; on MI355X a whole head fits one workgroup, so they
-    do not change anything.  ``mask`` is not supported by the kernel and must be None."""
+    do not change anything.  Self-attention without a mask (the ViT path) runs the kernels of csrc/attention.hip; a mask
+    ((b, k_len) key padding or anything broadcastable to (b, h, q_len, k_len), True = attend; utils.py:156-164) or
+    q_len != k_len (cross-attention) runs the general kernels of csrc/attention_x.hip (exact fp32).  `causal` together with
+    k_len > q_len raises: the reference shifts the diagonal the wrong way there (utils.py:169: the first k_len - q_len
+    queries see no key, and what it returns for them depends on the bucket sizes)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, q, k, v, mask, causal, q_bucket_size, k_bucket_size):
-        if mask is not None:
-            raise NotImplementedError("key-padding masks are not implemented in the HIP attention kernel")
-        if tuple(k.shape) != tuple(q.shape) or tuple(v.shape) != tuple(q.shape):
-            # the reference tiles over independent q / k lengths (utils.py:150-160); the HIP kernel holds one head of ONE
-            # length in a work-group, so cross-attention (FlashAttention(context=...)) is rejected instead of mis-read
-            raise NotImplementedError(f"q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)}: the HIP attention kernel "
-                                      "needs q, k and v of one shape (self-attention)")
+        if q.dim() != 4 or k.dim() != 4 or tuple(v.shape) != tuple(k.shape) or k.shape[:2] != q.shape[:2] or k.shape[3] != q.shape[3]:
+            raise ValueError(f"q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)}: need q (b, h, q_len, d) and k, v (b, h, k_len, d)")
+        if causal and k.shape[2] > q.shape[2]:
+            raise NotImplementedError(f"causal attention with k_len {k.shape[2]} > q_len {q.shape[2]}: the reference shifts the diagonal so that "
+                                      "the first k_len - q_len queries see no key (utils.py:169,183) and answers bucket-size dependently; refused")
         q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
         scale = q.shape[-1] ** -0.5
         o = torch.empty(q.shape, device=q.device, dtype=q.dtype)
-        lse = ops._attn_fwd(q, k, v, o, causal, scale)
-        ctx.args = (causal, scale)
-        ctx.save_for_backward(q, k, v, o, lse)
+        general = mask is not None or k.shape[2] != q.shape[2]
+        if mask is not None:
+            if mask.dim() == 2:
+                mask = mask[:, None, None, :]                         # 'b n -> b 1 1 n' (utils.py:156-157)
+            mask = mask.to(device=q.device, dtype=torch.bool).expand(q.shape[0], q.shape[1], q.shape[2], k.shape[2])
+        if general:
+            lse = ops._attn_x_fwd(q, k, v, o, mask, causal, scale)
+        else:
+            lse = ops._attn_fwd(q, k, v, o, causal, scale)
+        ctx.args = (causal, scale, general)
+        ctx.save_for_backward(q, k, v, o, lse, mask)
         return o
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, do):
-        causal, scale = ctx.args
-        q, k, v, o, lse = ctx.saved_tensors
+        causal, scale, general = ctx.args
+        q, k, v, o, lse, mask = ctx.saved_tensors
         do = do.float().contiguous()
         dq, dk, dv = (torch.empty_strided(t.shape, t.stride(), device=t.device, dtype=t.dtype) for t in (q, k, v))
-        ops._attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale)
+        if general:
+            ops._attn_x_bwd(q, k, v, o, lse, do, dq, dk, dv, mask, causal, scale)
+        else:
+            ops._attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale)
         return dq, dk, dv, None, None, None, None
 
 

@@ -361,15 +361,41 @@ def msa_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_heads: int, fai
 # --------------------------------------------------------------------------
 # a7  FlashAttentionFunction          utils.py:134-295 ; FlashAttention attention.py:13-109
 # --------------------------------------------------------------------------
-def attention_reference(q: Tensor, k: Tensor, v: Tensor, causal: bool = False) -> Tuple[Tensor, Tensor]:
-    """Dense softmax(q k^T d^-1/2) v and the row log-sum-exp; (..., N, D) inputs."""
+def attention_dead(q: Tensor, k: Tensor, causal: bool = False, mask: Optional[Tensor] = None) -> Optional[Tensor]:
+    """Boolean [.., q_len, k_len] map of the positions FlashAttentionFunction excludes: a mask entry that is False (a (b, n)
+    key-padding mask is viewed as (b, 1, 1, n), utils.py:156-157) and, with `causal`, key j > query i (utils.py:178-190:
+    triu(q_start_index - k_start_index + 1)).  causal with k_len > q_len is refused: there utils.py:169 subtracts
+    qk_len_diff from q_start_index, query i sees keys j <= i - (k_len - q_len), the first k_len - q_len queries see none and
+    the reference's answer for them depends on the bucket sizes (uniform weights over causally masked keys of some buckets)."""
+    nq, nk = q.shape[-2], k.shape[-2]
+    if causal and nk > nq:
+        raise ValueError("causal attention with k_len > q_len is ill-defined in the reference (utils.py:169,183)")
+    dead = None
+    if mask is not None:
+        if mask.dim() == 2:
+            mask = mask[:, None, None, :]
+        dead = ~mask.to(torch.bool).expand(q.shape[:-2] + (nq, nk))
+    if causal:
+        c = torch.ones(nq, nk, dtype=torch.bool).triu(1)
+        dead = c.expand(q.shape[:-2] + (nq, nk)) if dead is None else (dead | c)
+    return dead
+
+
+def attention_reference(q: Tensor, k: Tensor, v: Tensor, causal: bool = False, mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Dense softmax(q k^T d^-1/2) v and the row log-sum-exp; q (..., q_len, D), k / v (..., k_len, D); excluded positions
+    (attention_dead) take no weight; a query with no live key gets o = 0 (the reference's clamp(min=EPSILON) row sum,
+    utils.py:204-205,223) and lse = -max."""
     scale = q.shape[-1] ** -0.5
     s = (q @ k.transpose(-1, -2)) * scale
-    if causal:
-        nq, nk = s.shape[-2:]
-        s = s.masked_fill(torch.ones(nq, nk, dtype=torch.bool).triu(nk - nq + 1), -torch.finfo(s.dtype).max)
+    dead = attention_dead(q, k, causal, mask)
+    if dead is None:
+        return torch.softmax(s, dim=-1) @ v, torch.logsumexp(s, dim=-1)
+    s = s.masked_fill(dead, -torch.finfo(s.dtype).max)
+    p = torch.softmax(s, dim=-1).masked_fill(dead, 0.0)
     lse = torch.logsumexp(s, dim=-1)
-    return torch.softmax(s, dim=-1) @ v, lse
+    none_live = dead.all(dim=-1)
+    lse = torch.where(none_live, torch.full_like(lse, -torch.finfo(s.dtype).max), lse)
+    return p @ v, lse
 
 
 def flash_attention_tiled(q: Tensor, k: Tensor, v: Tensor, q_bucket: int, k_bucket: int) -> Tuple[Tensor, Tensor]:
@@ -397,13 +423,19 @@ def flash_attention_tiled(q: Tensor, k: Tensor, v: Tensor, q_bucket: int, k_buck
     return o, lse
 
 
-def flash_attention_backward(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: Tensor
-                             ) -> Tuple[Tensor, Tensor, Tensor]:
+def flash_attention_backward(q: Tensor, k: Tensor, v: Tensor, o: Tensor, lse: Tensor, do: Tensor, causal: bool = False,
+                             mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """Recompute-based backward (utils.py:229-295) without tiling:
-    p = exp(s - lse); dv = p^T do; dp = do v^T; D = rowsum(do*o);
+    p = exp(s - lse) (0 on excluded positions, utils.py:272-281); dv = p^T do; dp = do v^T; D = rowsum(do*o);
     ds = p*scale*(dp - D); dq = ds k; dk = ds^T q."""
     scale = q.shape[-1] ** -0.5
-    p = torch.exp((q @ k.transpose(-1, -2)) * scale - lse.unsqueeze(-1))
+    s = (q @ k.transpose(-1, -2)) * scale
+    dead = attention_dead(q, k, causal, mask)
+    if dead is not None:
+        s = s.masked_fill(dead, -torch.finfo(s.dtype).max)
+    p = torch.exp(s - lse.unsqueeze(-1))
+    if dead is not None:
+        p = p.masked_fill(dead, 0.0)
     dv = p.transpose(-1, -2) @ do
     dp = do @ v.transpose(-1, -2)
     dsum = (do * o).sum(dim=-1, keepdim=True)

@@ -230,6 +230,55 @@ def gen_flash():
     print("flash done")
 
 
+def gen_flash_x():
+    """FlashAttentionFunction beyond the ViT path: key-padding / full masks and q_len != k_len (utils.py:141-195, 229-295),
+    the reference's own outputs and gradients for the general attention kernels (csrc/attention_x.hip).  Not generated: causal
+    with k_len > q_len -- utils.py:169,183 shift the diagonal the wrong way (q_start_index = ind*bucket MINUS qk_len_diff: query i
+    sees keys j <= i - (k_len - q_len)), so the first k_len - q_len queries have no visible key and the reference returns a
+    bucket-size dependent average over causally masked keys for them; this build refuses that combination."""
+    g = torch.Generator().manual_seed(11)
+    cases = {
+        # tag: (b, h, q_len, k_len, d, causal, mask kind, (q_bucket, k_bucket))
+        "keypad": (2, 3, 50, 50, 32, False, "bn", (32, 16)),
+        "cross": (2, 2, 37, 197, 64, False, None, (512, 1024)),
+        "cross_mask4": (2, 2, 70, 33, 64, False, "b1qk", (64, 16)),
+        "short_causal": (1, 2, 60, 24, 16, True, None, (512, 1024)),
+        "keypad_causal": (2, 2, 45, 45, 32, True, "bn_tail", (512, 1024)),
+    }
+    blob = {}
+    for tag, (b, h, nq, nk, d, causal, mk, (qb, kb)) in cases.items():
+        q = torch.randn(b, h, nq, d, generator=g).requires_grad_(True)
+        k = torch.randn(b, h, nk, d, generator=g).requires_grad_(True)
+        v = torch.randn(b, h, nk, d, generator=g).requires_grad_(True)
+        do = torch.randn(b, h, nq, d, generator=g)
+        mask = None
+        if mk == "bn":
+            mask = torch.rand(b, nk, generator=g) > 0.3
+            mask[:, 0] = True
+        elif mk == "bn_tail":                    # padding at the end of the sequence; key 0 stays visible to every causal row
+            mask = torch.ones(b, nk, dtype=torch.bool)
+            mask[0, nk - 7:] = False
+            mask[1, nk - 20:] = False
+        elif mk == "b1qk":
+            mask = torch.rand(b, 1, nq, nk, generator=g) > 0.4
+            mask[..., 0] = True                  # every query keeps at least one key
+        o = FlashAttentionFunction.apply(q, k, v, mask, causal, qb, kb)
+        o.backward(do)
+        blob[f"{tag}.q"], blob[f"{tag}.k"], blob[f"{tag}.v"], blob[f"{tag}.do"] = npy(q), npy(k), npy(v), npy(do)
+        blob[f"{tag}.o"], blob[f"{tag}.dq"], blob[f"{tag}.dk"], blob[f"{tag}.dv"] = npy(o), npy(q.grad), npy(k.grad), npy(v.grad)
+        blob[f"{tag}.causal"] = np.array(int(causal))
+        if mask is not None:
+            blob[f"{tag}.mask"] = mask.numpy()
+    # a fully masked batch row: o = 0 through the reference's clamp(min=EPSILON) row sum
+    q, k, v = (torch.randn(2, 1, 8, 16, generator=g) for _ in range(3))
+    mask = torch.ones(2, 8, dtype=torch.bool)
+    mask[1] = False
+    o = FlashAttentionFunction.apply(q, k, v, mask, False, 512, 1024)
+    blob["allmasked.q"], blob["allmasked.k"], blob["allmasked.v"], blob["allmasked.mask"], blob["allmasked.o"] = npy(q), npy(k), npy(v), mask.numpy(), npy(o)
+    np.savez_compressed(os.path.join(OUT, "flash_x.npz"), **blob)
+    print("flash_x done")
+
+
 def build_reference_vit(chw, n_patches, n_blocks, d, heads, out_d, t):
     """Instantiate the reference model; apply the D3/D4 harness adapters when needed."""
     adapter = 0
@@ -338,7 +387,7 @@ def gen_misc():
 if __name__ == "__main__":
     only = set(sys.argv[1:])                   # e.g. `make_golden.py msa197 metrics` regenerates just those files
     gens = {"misc": gen_misc, "layers": gen_layers, "msa": gen_msa, "msa197": gen_msa_big, "metrics": gen_metrics,
-            "flash": gen_flash, "models": gen_models}
+            "flash": gen_flash, "flash_x": gen_flash_x, "models": gen_models}
     for name, fn in gens.items():
         if not only or name in only:
             fn()

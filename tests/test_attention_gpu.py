@@ -185,24 +185,132 @@ def test_small_head_kernels_packed_layout_and_determinism(b, h, n, d, causal):
     assert rel_err(o1, o0) < 1e-5 and rel_err(g1, g0) < 1e-5
 
 
-def test_cross_attention_shapes_are_refused_not_misread():
-    """kanvit_attn_desc carries ONE sequence length: a shorter k/v would be read out of bounds and a longer one silently
-    truncated (the reference's FlashAttentionFunction accepts q_len != k_len, utils.py:150-160).  Both the module-level
-    function and the op-level binding must raise before anything is launched."""
+def test_self_attention_binding_refuses_other_shapes():
+    """kanvit_attn_desc carries ONE sequence length: through the self-attention binding a shorter k/v would be read out of bounds
+    and a longer one silently truncated, so ops.attention raises before anything is launched (FlashAttentionFunction routes
+    q_len != k_len and masks to the general kernels instead, below)."""
     from kanvit import ops
     from kanvit._lib import KanvitError
     from utils import FlashAttentionFunction
     q = torch.randn(2, 2, 40, 32, device=DEV)
     for nk in (24, 56):
         k = torch.randn(2, 2, nk, 32, device=DEV)
-        with pytest.raises(NotImplementedError):
-            FlashAttentionFunction.apply(q, k, k, None, False, 512, 512)
         with pytest.raises(KanvitError):
             ops.attention(q, k, k)
     with pytest.raises(KanvitError):                                    # head-size mismatch
         ops.attention(q, torch.randn(2, 2, 40, 16, device=DEV), torch.randn(2, 2, 40, 16, device=DEV))
-    with pytest.raises(NotImplementedError):                            # key-padding masks: out of scope, loud
-        FlashAttentionFunction.apply(q, q, q, torch.ones(2, 40, dtype=torch.bool, device=DEV), False, 512, 512)
+    with pytest.raises(ValueError):
+        FlashAttentionFunction.apply(q, torch.randn(2, 2, 40, 16, device=DEV), torch.randn(2, 2, 40, 16, device=DEV), None, False, 512, 512)
+    # causal with k_len > q_len: the reference's diagonal runs the wrong way (utils.py:169,183) -- refused, at both levels
+    k = torch.randn(2, 2, 56, 32, device=DEV)
+    with pytest.raises(NotImplementedError):
+        FlashAttentionFunction.apply(q, k, k, None, True, 512, 512)
+    with pytest.raises(KanvitError, match="ill-defined"):
+        ops._attn_x_fwd(q, k, k, torch.empty_like(q), None, True, 32 ** -0.5)
+    # the swept operand of a head must fit the LDS
+    kl = torch.randn(1, 1, 300, 64, device=DEV)
+    with pytest.raises(KanvitError, match="LDS"):
+        ops._attn_x_fwd(q[:1, :1, :, :].repeat(1, 1, 1, 2).contiguous(), kl, kl, torch.empty(1, 1, 40, 64, device=DEV), None, False, 0.125)
+
+
+FLASH_X_CASES = ["keypad", "cross", "cross_mask4", "short_causal", "keypad_causal"]
+
+
+@pytest.mark.parametrize("tag", FLASH_X_CASES)
+def test_flash_function_masks_and_cross_lengths_against_reference_fixture(tag):
+    """FlashAttentionFunction with a key-padding / full mask and with q_len != k_len (utils.py:141-195, 229-295) against the
+    reference's own outputs and gradients (tests/golden/flash_x.npz): the general kernels of csrc/attention_x.hip."""
+    from utils import FlashAttentionFunction
+    f = load_npz("flash_x.npz")
+    q, k, v = (T(f[f"{tag}.{n}"]).to(DEV).requires_grad_(True) for n in ("q", "k", "v"))
+    do = T(f[f"{tag}.do"]).to(DEV)
+    causal = bool(int(f[f"{tag}.causal"]))
+    mask = torch.from_numpy(f[f"{tag}.mask"]).to(DEV) if f"{tag}.mask" in f else None
+    o = FlashAttentionFunction.apply(q, k, v, mask, causal, 512, 1024)
+    o.backward(do)
+    assert max_err(o.cpu(), T(f[f"{tag}.o"])) < 5e-6
+    assert max_err(q.grad.cpu(), T(f[f"{tag}.dq"])) < 2e-5
+    assert max_err(k.grad.cpu(), T(f[f"{tag}.dk"])) < 2e-5
+    assert max_err(v.grad.cpu(), T(f[f"{tag}.dv"])) < 2e-5
+
+
+def test_flash_function_fully_masked_sample():
+    from utils import FlashAttentionFunction
+    f = load_npz("flash_x.npz")
+    q, k, v = (T(f[f"allmasked.{n}"]).to(DEV).requires_grad_(True) for n in ("q", "k", "v"))
+    mask = torch.from_numpy(f["allmasked.mask"]).to(DEV)
+    o = FlashAttentionFunction.apply(q, k, v, mask, False, 512, 1024)
+    assert max_err(o.cpu(), T(f["allmasked.o"])) < 5e-6 and float(o[1].abs().max()) == 0.0
+    o.sum().backward()
+    for t in (q, k, v):
+        assert torch.isfinite(t.grad).all() and float(t.grad[1].abs().max()) == 0.0     # nothing flows through the masked sample
+
+
+@pytest.mark.parametrize("nq,nk", [(1, 1), (7, 50), (50, 7), (33, 64), (64, 33), (197, 50), (50, 197), (224, 224), (130, 97)])
+@pytest.mark.parametrize("d", [2, 8, 32, 64])
+@pytest.mark.parametrize("kind", ["none", "keypad", "full", "full_heads", "causal", "causal_keypad"])
+def test_general_attention_against_fp64_oracle(nq, nk, d, kind):
+    """The general kernels over lengths (ragged tiles on both sides, one side longer than the other), head sizes and mask
+    layouts -- (b, n) key padding, (b, 1, q, k) and (b, h, q, k) masks, strided (expanded) mask views -- against the float64
+    oracle, forward and all three gradients; bitwise run-to-run."""
+    from utils import FlashAttentionFunction
+    causal = kind.startswith("causal")
+    if causal and nk > nq:
+        pytest.skip("causal with k_len > q_len is refused (ill-defined in the reference)")
+    g = torch.Generator().manual_seed(nq * 131 + nk * 7 + d)
+    b, h = 2, 3
+    q = torch.randn(b, h, nq, d, generator=g) * 1.3
+    k = torch.randn(b, h, nk, d, generator=g) * 1.3
+    v = torch.randn(b, h, nk, d, generator=g)
+    do = torch.randn(b, h, nq, d, generator=g)
+    mask = None
+    if kind in ("keypad", "causal_keypad"):
+        mask = torch.rand(b, nk, generator=g) > 0.35
+        mask[:, 0] = True
+    elif kind == "full":
+        mask = torch.rand(b, 1, nq, nk, generator=g) > 0.5
+        mask[..., 0] = True
+    elif kind == "full_heads":
+        mask = torch.rand(b, h, nq, nk, generator=g) > 0.5
+        mask[..., 0] = True
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = ko.attention_reference(qd, kd, vd, causal=causal, mask=mask)
+    o_ref.backward(do.double())
+    outs = []
+    for _ in range(2):
+        qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        o = FlashAttentionFunction.apply(qg, kg, vg, None if mask is None else mask.to(DEV), causal, 512, 1024)
+        o.backward(do.to(DEV))
+        outs.append((o.detach(), qg.grad, kg.grad, vg.grad))
+    if nq == nk and mask is None:
+        pass                                        # (self-attention without a mask: the ViT kernels, covered above)
+    assert max_err(outs[0][0].cpu(), o_ref) < 1e-5
+    assert close(outs[0][1], qd.grad) and close(outs[0][2], kd.grad) and close(outs[0][3], vd.grad)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+
+
+def test_flash_attention_module_with_context_and_mask():
+    """FlashAttention(x, context=..., mask=...) (attention.py:59-109): projections around the general attention core, against
+    the same computation in float64 with the oracle's attention."""
+    from attention import FlashAttention
+    torch.manual_seed(3)
+    m = FlashAttention(dim=48, heads=3, dim_head=32).to(DEV)
+    x = torch.randn(2, 21, 48, device=DEV, requires_grad=True)
+    ctxt = torch.randn(2, 77, 48, device=DEV, requires_grad=True)
+    mask = torch.rand(2, 77, device=DEV) > 0.3
+    mask[:, 0] = True
+    y = m(x, context=ctxt, mask=mask)
+    y.square().sum().backward()
+    W = {n: p.detach().cpu().double() for n, p in m.named_parameters()}
+    xd, cd = x.detach().cpu().double().requires_grad_(True), ctxt.detach().cpu().double().requires_grad_(True)
+    qd = (xd @ W["to_q.weight"].T).view(2, 21, 3, 32).permute(0, 2, 1, 3)
+    kd, vd = ((cd @ W["to_kv.weight"].T).chunk(2, dim=-1)[i].reshape(2, 77, 3, 32).permute(0, 2, 1, 3) for i in range(2))
+    od, _ = ko.attention_reference(qd, kd, vd, mask=mask.cpu())
+    yd = od.permute(0, 2, 1, 3).reshape(2, 21, 96) @ W["to_out.weight"].T
+    yd.square().sum().backward()
+    assert rel_err(y.detach().cpu(), yd.detach()) < 1e-5
+    assert rel_err(x.grad.cpu(), xd.grad) < 1e-4 and rel_err(ctxt.grad.cpu(), cd.grad) < 1e-4
 
 
 @pytest.mark.parametrize("n", [65, 96, 127, 128, 129, 160, 197, 200, 201, 208])

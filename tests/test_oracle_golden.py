@@ -153,6 +153,34 @@ def test_flash_attention_function():
     assert max_err(oc, T(f["causal.o"])) < 2e-6
 
 
+FLASH_X_CASES = ["keypad", "cross", "cross_mask4", "short_causal", "keypad_causal"]
+
+
+@pytest.mark.parametrize("tag", FLASH_X_CASES)
+def test_flash_attention_function_masks_and_cross_lengths(tag):
+    """The oracle's restatement of the mask / q_len != k_len semantics (utils.py:141-195, 229-295) against the reference's own
+    outputs and gradients (tests/golden/flash_x.npz, make_golden.py::gen_flash_x)."""
+    f = load_npz("flash_x.npz")
+    q, k, v, do = (T(f[f"{tag}.{n}"]) for n in ("q", "k", "v", "do"))
+    causal = bool(int(f[f"{tag}.causal"]))
+    mask = torch.from_numpy(f[f"{tag}.mask"]) if f"{tag}.mask" in f else None
+    o, lse = ko.attention_reference(q, k, v, causal=causal, mask=mask)
+    assert max_err(o, T(f[f"{tag}.o"])) < 3e-6
+    dq, dk, dv = ko.flash_attention_backward(q, k, v, o, lse, do, causal=causal, mask=mask)
+    assert max_err(dq, T(f[f"{tag}.dq"])) < 2e-5
+    assert max_err(dk, T(f[f"{tag}.dk"])) < 2e-5
+    assert max_err(dv, T(f[f"{tag}.dv"])) < 2e-5
+
+
+def test_flash_attention_function_fully_masked_row():
+    f = load_npz("flash_x.npz")
+    q, k, v = (T(f[f"allmasked.{n}"]) for n in ("q", "k", "v"))
+    mask = torch.from_numpy(f["allmasked.mask"])
+    o, lse = ko.attention_reference(q, k, v, mask=mask)
+    assert max_err(o, T(f["allmasked.o"])) < 3e-6 and float(o[1].abs().max()) == 0.0
+    assert float(T(f["allmasked.o"])[1].abs().max()) == 0.0          # the reference's own answer for the fully masked sample
+
+
 TYPES = ["vanilla", "flash-attn", "efficientkan", "sine", "fourier", "cheby", "fast"]
 
 
