@@ -530,8 +530,8 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
     switch (family) {
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
         case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1, 5, true, true>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3, 5, true, true>(a, p, bf, st);
-        case KANVIT_BSPLINE:      // exact fp32 only (the plan refuses bf16 mode: there the LDS-tile bf16 kernel runs)
-            return p.nt == 3 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 3, 5, false>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 5, false>(a, p, bf, st);
+        case KANVIT_BSPLINE:      // two windows of five basis slots (exact fp32 when the 16-row kernel does not apply; bf16 mode)
+            return p.nt == 3 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 3, 5, true, true>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 5, true>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:
             if (a.flags & KANVIT_FLAG_SINE_DFREQ) {      // the x * cos operand (d loss / d freq through a weight-gradient pass; kanvit.h)
@@ -561,8 +561,10 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // MFMAs per basis evaluation), a window evaluating only its own values (compile-time window start).  The idle slot
     // costs 10 % of the MFMAs; 3 x 6 tiles (no idle slot, 288 accumulators) and round 2's 9 x 2 both spill accumulators
     // inside the token loop (the allocator cannot place more than 256 of them) and lose to the LDS-tile kernel.
+    // (bf16 mode runs the same two-window schedule on v_mfma_f32_32x32x16_bf16; the LDS-tile bf16 kernel it replaces there was slower
+    // than the exact 16-row kernel: 0.76 vs 0.70 ms on the ViT-B q|k|v launch)
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 && d->has_base &&
-             !((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16)) { p.nt = 3; p.njc = 2; }
+             !((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16 && kv_config().bs_bw_bf16 == 1)) { p.nt = 3; p.njc = 2; }
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
     else if (fam == KANVIT_SINE && (p.gp == 4 || p.gp == 5)) p.nt = 2;
     // SINE G = 28: windows of 4 basis functions x 4 column tiles.  (Windows of 2 x 6 tiles -- 12 MFMAs per pair of sines instead
@@ -576,8 +578,10 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // slot, two waves per SIMD -- when the 16-column tiles of a basis group divide by 12 or 4 (q|k|v of a 64-wide head: 12)
     // FastKAN (exact fp32): the same kernel with all nine values x 4 column tiles of 16 per wave (its q, k, v do not share u):
     // 36 MFMAs per evaluation of the eight Gaussians + silu instead of 18
-    const bool bf16_mode = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
-    if (((fam == KANVIT_BSPLINE && p.njc == 2) || (fam == KANVIT_RBF && !bf16_mode)) && !kv_config().bw_no_t16) {
+    bool bf16_mode = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
+    if (fam == KANVIT_BSPLINE && bf16_mode && kv_config().bs_bw_bf16 != 3) bf16_mode = false;       // B-splines under the bf16 flag: the exact 16-row kernel (the flag allows, never requires, bf16 products)
+    p.bf = bf16_mode ? 1 : 0;
+    if (((fam == KANVIT_BSPLINE && p.njc == 2) || fam == KANVIT_RBF) && !bf16_mode && !kv_config().bw_no_t16) {
         const int sh = (kv_share_ok(fam, d->flags) && nshare > 1) ? 1 : 0;
         const int t16 = (sh ? nshare : 1) * (d->O / 16);
         const int nc = (fam != KANVIT_RBF && t16 % 12 == 0) ? 12 : ((t16 % 4 == 0) ? 4 : 0);      // else: the 32-row kernel below
@@ -663,6 +667,7 @@ bool kv_bwd_weight_reg_pg_ok(const kanvit_layer_desc* d, const BwRegPlan& p) {
     if (!p.ok || d->groups != 1) return false;
     if (p.t16) return d->family == KANVIT_BSPLINE;
     switch (d->family) {
+        case KANVIT_BSPLINE: return p.nt == 3;
         case KANVIT_CHEBY: return p.gp == 5 && (p.nt == 3 || p.nt == 1);
         case KANVIT_SINE: return p.gp == 28;
         case KANVIT_FOURIER: return p.gp == 56;

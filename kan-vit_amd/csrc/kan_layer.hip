@@ -136,9 +136,10 @@ static void kv_config_load() {
     c.ff_grid = num("KANVIT_FF_GRID");
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
+    c.bs_bw_bf16 = num("KANVIT_BSPLINE_BW_BF16");
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d",
-             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid);
+             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d bs_bw_bf16=%d",
+             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid, c.bs_bw_bf16);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }
@@ -355,7 +356,7 @@ int kanvit_patch_embed_bwd_weight(const kanvit_layer_desc* d, const kanvit_patch
     a.dy = dy;
     patch_args(a, p, nullptr, nullptr);
     hipStream_t st = (hipStream_t)stream;
-    const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
+    const bool bf = pr.bf != 0;
     a.rows_per_split = pr.rows_per_slab;
     a.msplit = pr.slabs;
     a.slab = (pr.slabs > 1) ? (float*)workspace : dw;
@@ -498,7 +499,7 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
         if (!pr.ok && a.ln) return kv_fail(KANVIT_EINVAL, "kanvit_layer_bwd_weight: KANVIT_FLAG_FUSED_LN needs the register kernel (shape)");
         if (pr.ok) {
             hipStream_t st = (hipStream_t)stream;
-            const bool bf = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
+            const bool bf = pr.bf != 0;
             a.rows_per_split = pr.rows_per_slab;
             a.msplit = pr.slabs;
             a.slab = (pr.slabs > 1) ? (float*)workspace : dw;

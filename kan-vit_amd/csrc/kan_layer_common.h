@@ -223,6 +223,7 @@ struct BwRegPlan {
     bool ok;
     int gp, nt, nfb, nos, tiles_per_bg, nbg, shared, slabs, njc;
     int t16;              // 1: the 16-row-tile kernel (nt = 16-column tiles per wave, nfb = 16-feature blocks)
+    int bf;               // 1: the planned kernel contracts on the bf16 matrix cores (KANVIT_FLAG_BF16_MFMA allows it; the exact kernels ignore it)
     long long rows_per_slab;
     size_t ws_bytes;
 };

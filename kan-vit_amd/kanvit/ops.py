@@ -476,6 +476,8 @@ def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale, flags=0):
 def _attn_x_desc(q, k, v, o, mask, causal: bool, scale: float):
     """Descriptor pair of the general attention kernels (kanvit_attn_x_*): q, o [B, H, Nq, D]; k, v [B, H, Nk, D]; mask None or a
     torch.bool tensor already expanded (views, no copy) to [B, H, Nq, Nk]."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        _require_gpu_f32(n, t)
     B, H, Nq, D = q.shape
     Nk = k.shape[2]
     if tuple(k.shape) != (B, H, Nk, D) or tuple(v.shape) != (B, H, Nk, D) or tuple(o.shape) != (B, H, Nq, D):

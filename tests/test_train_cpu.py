@@ -71,16 +71,21 @@ def test_mixed_block_types_keep_the_reference_layout_per_block():
         VisionTransformer(**geo, type="")
 
 
-def test_attention_rejects_cross_attention_shapes():
-    """kanvit_attn_desc has ONE sequence length: q / k / v of different lengths must raise before any launch (the reference's
-    FlashAttentionFunction tiles over independent lengths, utils.py:150-160 -- documented limit)."""
+def test_attention_shape_checks_happen_before_any_launch():
+    """The self-attention binding (kanvit_attn_desc: ONE sequence length) refuses q / k / v of different shapes before any launch;
+    FlashAttentionFunction routes q_len != k_len and masks to the general kernels (kanvit_attn_x_*), which -- like every kanvit
+    op -- refuse CPU tensors instead of falling back, and refuses `causal` with k_len > q_len (utils.py:169,183: ill-defined)."""
     from utils import FlashAttentionFunction
+    from kanvit import KanvitError, ops
     q = torch.randn(1, 2, 8, 16)
     for kv_len in (5, 12):
         k = torch.randn(1, 2, kv_len, 16)
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(KanvitError):                                # CPU tensors: no fallback
             FlashAttentionFunction.apply(q, k, k, None, False, 512, 1024)
-    from kanvit import KanvitError, ops
+    with pytest.raises(NotImplementedError):
+        FlashAttentionFunction.apply(q, torch.randn(1, 2, 12, 16), torch.randn(1, 2, 12, 16), None, True, 512, 1024)
+    with pytest.raises(ValueError):                                     # v does not match k
+        FlashAttentionFunction.apply(q, torch.randn(1, 2, 12, 16), torch.randn(1, 2, 11, 16), None, False, 512, 1024)
     with pytest.raises(KanvitError):
         ops._attn_desc(q, torch.randn(1, 2, 5, 16), q, q, False, 0.25)
     with pytest.raises(KanvitError):
