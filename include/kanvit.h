@@ -184,9 +184,10 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
  * backward leaves it (class-token rows are stepped over): no transient [B*P, I] patch matrix, no copy of dY.  d as above
  * (M = B*P, `ldy` = row stride of dy); KANVIT_FLAG_BF16_MFMA and KANVIT_FLAG_SINE_DFREQ as for kanvit_layer_bwd_weight.
  * kanvit_patch_embed_bwd_weight_ok() (pure host function) says whether the gathering kernels cover the layer: the patch
- * embeddings VisionTransformer builds (model.py:67-80: ChebyKAN degree 4, efficient-KAN in exact fp32, SineKAN and
- * FourierKAN at grid 28; I, O multiples of 32, 32-bit element offsets); otherwise the call returns KANVIT_EINVAL and the
- * caller uses patchify + kanvit_layer_bwd_weight. */
+ * embeddings VisionTransformer builds (model.py:67-80) with ChebyKAN degree 4, SineKAN and FourierKAN at grid 28 (I, O
+ * multiples of 32, M >= 256, 32-bit element offsets); otherwise (efficient-KAN: its weight-gradient kernels have no register
+ * left for the row walker and measured slower with it) the call returns KANVIT_EINVAL and the caller uses patchify +
+ * kanvit_layer_bwd_weight. */
 typedef struct kanvit_patch_desc {
     int32_t C, H, W;         /* image batch is [B][C][H][W], contiguous                                  */
     int32_t n_patches;       /* patches per side: patch = (H / n_patches) x (W / n_patches) pixels       */

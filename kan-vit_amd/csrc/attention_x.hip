@@ -57,6 +57,23 @@ __device__ __forceinline__ bool x_dead(const AttnXArgs& a, const unsigned char* 
     return false;
 }
 
+// Dead positions of one 32x32 accumulator tile as a bit per accumulator register.  The mask bytes are read HERE, before the
+// accumulators are touched: with the loads inside the select on the accumulator value, hipcc 7.2 reused the register holding the
+// element for the loaded byte and every masked launch returned wrong numbers (an all-true mask changed the result).
+// KEY_IN_REG: the register index runs over keys and the lane is the query (forward, dQ); else the register index runs over queries
+// and the lane is the key (dK, dV).
+template <bool KEY_IN_REG>
+__device__ __forceinline__ unsigned x_dead_bits(const AttnXArgs& a, const unsigned char* mrow_base, int lane_index, int tile0, int hf) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int reg_index = tile0 + kv_acc_row(r, hf);
+        const bool d = KEY_IN_REG ? x_dead(a, mrow_base, lane_index, reg_index) : x_dead(a, mrow_base, reg_index, lane_index);
+        bits |= (d ? 1u : 0u) << r;
+    }
+    return bits;
+}
+
 // dst[rows][KS] <- src rows row0.. (row stride stride_n), zero beyond n_valid rows and D columns
 template <int DT>
 __device__ __forceinline__ void x_load_tile(float* __restrict__ dst, const float* __restrict__ src, long long stride_n, int row0,
@@ -122,14 +139,16 @@ __global__ __launch_bounds__(XTHR) void attn_x_fwd_kernel(const AttnXArgs a) {
             }
         }
         const int qrow = qt * 32 + l31;
+        unsigned dbits[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) dbits[j] = (j < nkt) ? x_dead_bits<true>(a, mb, qrow, j * 32, hf) : 0xffffu;
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NKT; ++j) {
             if (j < nkt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = j * 32 + kv_acc_row(r, hf);
-                    const float sv = x_dead(a, mb, qrow, key) ? -INFINITY : sacc[j][r];
+                    const float sv = ((dbits[j] >> r) & 1u) ? -INFINITY : sacc[j][r];
                     sacc[j][r] = sv;
                     mx = fmaxf(mx, sv);
                 }
@@ -270,11 +289,12 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) 
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * s], kf[s], sacc, 0, 0, 0);      // S[q][key]
                 pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[2 * s], vf[s], pacc, 0, 0, 0);      // dP[q][key]
             }
+            const unsigned db = x_dead_bits<false>(a, mb, key, qt * 32, hf);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qrow = qt * 32 + kv_acc_row(r, hf);
                 float p = exp2f(sacc[r] * sc2 - lse_s[qrow]);
-                if (jt >= a.nkt || qrow >= a.Nq || x_dead(a, mb, qrow, key)) p = 0.0f;          // select, never multiply: exp2 may be inf on a dead row
+                if (jt >= a.nkt || qrow >= a.Nq || ((db >> r) & 1u)) p = 0.0f;          // select, never multiply: exp2 may be inf on a dead row
                 sacc[r] = p;
                 pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
                 if (p == 0.0f) pacc[r] = 0.0f;
@@ -366,11 +386,11 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc, 0, 0, 0);      // S^T[key][q]
                 pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], dof[s], pacc, 0, 0, 0);     // dP^T[key][q]
             }
+            const unsigned db = x_dead_bits<true>(a, mb, qrow, j * 32, hf);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = j * 32 + kv_acc_row(r, hf);
                 const float p = exp2f(sacc[r] * sc2 - lse2);
-                const bool dead = !q_ok || x_dead(a, mb, qrow, key);
+                const bool dead = !q_ok || ((db >> r) & 1u);
                 pacc[r] = dead ? 0.0f : p * a.scale * (pacc[r] - dl);                             // dS^T
             }
 #pragma unroll

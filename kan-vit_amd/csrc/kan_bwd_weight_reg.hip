@@ -122,10 +122,15 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         }
     }
     auto tok_of = [&](int blk, int t) -> int { return BF ? (16 * blk + 8 * hf + t) : (2 * (blk * UB + t) + hf); };
-    // patch gather: the walker stands on the first row of the next block to be requested (blocks are requested in order);
-    // rows past the slab take the slab's first row (their dY is zeroed when the block leaves the ring)
+    // patch gather: psx / psdy hold the x / dY offsets of the rows of the NEXT block to be requested (blocks are requested in order);
+    // rows past the slab take the slab's first row (their dY is zeroed when the block leaves the ring).  The walker that fills them is
+    // stepped row by row BETWEEN the MFMA groups of the block being contracted (walk_fill below): run as one cluster in front of the
+    // loads, its ~200 dependent scalar instructions per block sat in front of an idle matrix pipe (one wave per SIMD: +17 % on the
+    // ChebyKAN launch).
+    constexpr int TPB = BF ? 16 : 2 * UB;      // rows of a block: lane half hf takes rows 8hf + t (bf16) / 2t + hf (fp32)
     PatchWalk walk;
-    int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0;
+    int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0, pg_wtok = 0;
+    int psx[PG ? TPB : 1], psdy[PG ? TPB : 1];
     const int pg_hm = -hf;                       // all ones in the upper lane half
     if constexpr (PG) {
         walk.init(a, __builtin_amdgcn_readfirstlane((int)ms));
@@ -134,23 +139,23 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         pg_len = __builtin_amdgcn_readfirstlane(len);
         pg_f = kv_patch_feature_offset(a, f);
     }
+    auto walk_fill = [&](int k) {                // row k of the next block: the walker's row, then one step
+        if constexpr (PG) {
+            const bool in = pg_wtok < pg_len;
+            psx[k] = in ? walk.xoff : pg_x0;
+            psdy[k] = in ? walk.dyoff : pg_dy0;
+            walk.step();
+            ++pg_wtok;
+        }
+    };
     auto load_block = [&](int q, int blk) {
         if constexpr (PG) {
-            constexpr int TPB = BF ? 16 : 2 * UB;      // rows of a block: lane half hf takes rows 8hf + t (bf16) / 2t + hf (fp32)
-            int sx[TPB], sdy[TPB];
-#pragma unroll
-            for (int k = 0; k < TPB; ++k) {
-                const bool in = blk * TPB + k < pg_len;
-                sx[k] = in ? walk.xoff : pg_x0;
-                sdy[k] = in ? walk.dyoff : pg_dy0;
-                walk.step();
-            }
 #pragma unroll
             for (int t = 0; t < NTOK; ++t) {
                 // this lane's row is k0 (lower lane half) or k1 (upper): base + (difference & lane mask) -- written as a select, the
-                // pair becomes a dynamically indexed read of sx[] and a chain of seven v_cndmask per value
+                // pair becomes a dynamically indexed read of psx[] and a chain of seven v_cndmask per value
                 const int k0 = BF ? t : 2 * t, k1 = BF ? 8 + t : 2 * t + 1;
-                const int xo = sx[k0] + ((sx[k1] - sx[k0]) & pg_hm), dyr = sdy[k0] + ((sdy[k1] - sdy[k0]) & pg_hm);
+                const int xo = psx[k0] + ((psx[k1] - psx[k0]) & pg_hm), dyr = psdy[k0] + ((psdy[k1] - psdy[k0]) & pg_hm);
                 rx[q][t] = a.x[xo + pg_f];
 #pragma unroll
                 for (int i = 0; i < NOT; ++i) rdy[q][t][i] = a.dy[dyr + dyo[i]];
@@ -172,9 +177,19 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     };
     const int tok_per_blk = BF ? 16 : 2 * UB;
     const int nblk = (len + tok_per_blk - 1) / tok_per_blk;
+    if constexpr (PG) {
+#pragma unroll
+        for (int k = 0; k < TPB; ++k) walk_fill(k);
+    }
 #pragma unroll
     for (int q = 0; q < PD; ++q)
-        if (q < nblk) load_block(q, q);
+        if (q < nblk) {
+            load_block(q, q);
+            if constexpr (PG) {
+#pragma unroll
+                for (int k = 0; k < TPB; ++k) walk_fill(k);
+            }
+        }
 
     for (int blk0 = 0; blk0 < nblk; blk0 += PD) {
 #pragma unroll
@@ -203,6 +218,8 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                 if constexpr (!BF) {
 #pragma unroll
                     for (int t = 0; t < NTOK; ++t) {
+                        walk_fill(2 * t);                      // (patch gather) two rows of the next block per MFMA group
+                        walk_fill(2 * t + 1);
                         BasisGenP<FAM, JC, J0C> gen = proto;
                         gen.init(cx[t], RBF ? cu[t] : 0.0f);
 #pragma unroll
@@ -217,6 +234,8 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                     unsigned af[JC][4];
 #pragma unroll
                     for (int ep = 0; ep < 4; ++ep) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) walk_fill(4 * ep + k);      // (patch gather) the next block's rows, spread over the basis evaluations
                         BasisGenP<FAM, JC, J0C> g0_ = proto, g1_ = proto;
                         g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
                         g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
@@ -355,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
         float2 ru[RBF ? PD : 1][RBF ? UB : 1];      // FastKAN: u (in .x), or the token's (mean, rstd)
         auto tok_of = [&](int blk, int t) -> int { return 4 * (blk * UB + t) + tq; };
         PatchWalk walk;                       // patch gather: see kan_bwd_weight_reg_kernel
-        int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0;
+        int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0, pg_wtok = 0;
+        int psx[4], psdy[4];                  // offsets of the four rows of the next block to be requested
         const int pg_m1 = -(int)(tq == 1), pg_m2 = -(int)(tq == 2), pg_m3 = -(int)(tq == 3);
         if constexpr (PG) {
             static_assert(!PG || UB == 1, "one step of four rows per block");
@@ -365,20 +385,21 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
             pg_len = __builtin_amdgcn_readfirstlane(len);
             pg_f = kv_patch_feature_offset(a, f);
         }
+        auto walk_fill = [&](int k) {
+            if constexpr (PG) {
+                const bool in = pg_wtok < pg_len;
+                psx[k] = in ? walk.xoff : pg_x0;
+                psdy[k] = in ? walk.dyoff : pg_dy0;
+                walk.step();
+                ++pg_wtok;
+            }
+        };
         auto load_block = [&](int q, int blk) {
             if constexpr (PG) {
-                int sx[4], sdy[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool in = blk * 4 + k < pg_len;
-                    sx[k] = in ? walk.xoff : pg_x0;
-                    sdy[k] = in ? walk.dyoff : pg_dy0;
-                    walk.step();
-                }
                 // lane group tq takes row tq of the block: base + the masked differences (a select tree becomes a dynamically
-                // indexed read of sx[]: a v_cndmask chain per value)
-                const int xo = sx[0] + (((sx[1] - sx[0]) & pg_m1) | ((sx[2] - sx[0]) & pg_m2) | ((sx[3] - sx[0]) & pg_m3));
-                const int dyr = sdy[0] + (((sdy[1] - sdy[0]) & pg_m1) | ((sdy[2] - sdy[0]) & pg_m2) | ((sdy[3] - sdy[0]) & pg_m3));
+                // indexed read of psx[]: a v_cndmask chain per value)
+                const int xo = psx[0] + (((psx[1] - psx[0]) & pg_m1) | ((psx[2] - psx[0]) & pg_m2) | ((psx[3] - psx[0]) & pg_m3));
+                const int dyr = psdy[0] + (((psdy[1] - psdy[0]) & pg_m1) | ((psdy[2] - psdy[0]) & pg_m2) | ((psdy[3] - psdy[0]) & pg_m3));
                 rx[q][0] = a.x[xo + pg_f];
 #pragma unroll
                 for (int i = 0; i < NC; ++i) rdy[q][0][i] = a.dy[dyr + dyo[i]];
@@ -399,9 +420,19 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
             }
         };
         const int nblk = (len + 4 * UB - 1) / (4 * UB);
+        if constexpr (PG) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) walk_fill(k);
+        }
 #pragma unroll
         for (int q = 0; q < PD; ++q)
-            if (q < nblk) load_block(q, q);
+            if (q < nblk) {
+                load_block(q, q);
+                if constexpr (PG) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) walk_fill(k);
+                }
+            }
         // A block is copied out of the ring and its slot refilled BEFORE its MFMAs (prefetch distance PD blocks).  Reading the ring
         // registers directly and refilling after the MFMAs saves NC + 1 moves per step but shortens the distance to PD - 1 blocks:
         // measured slower (767 -> 812 us on the ViT-B q|k|v launch) -- at two waves per SIMD this kernel lives on its prefetch depth.
@@ -428,6 +459,10 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
                         gen.init(cx[t], cu[t]);
 #pragma unroll
                         for (int j = 0; j < JC; ++j) {
+                            if constexpr (PG) {                                   // the next block's four rows, spread over the JC MFMA groups
+                                if (JC >= 4) { if (j < 4) walk_fill(j); }
+                                else { walk_fill(j); if (j == JC - 1) for (int k = JC; k < 4; ++k) walk_fill(k); }
+                            }
                             const float av = ok[t] ? gen.next(j) : 0.0f;          // rows past the slab contribute nothing (JC selects, not NC)
 #pragma unroll
                             for (int i = 0; i < NC; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
@@ -525,13 +560,13 @@ int dispatch_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool b
     if (p.t16) {
         if (bf || (family != KANVIT_BSPLINE && family != KANVIT_RBF)) return kv_fail(KANVIT_EINVAL, "internal: 16-row weight-gradient dispatch");
         if (family == KANVIT_RBF) return launch_bwd_weight_reg16<KV_RBF, 9, 9, 4>(a, p, st);
-        return p.nt == 12 ? launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 12, true>(a, p, st) : launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 4, true>(a, p, st);
+        return p.nt == 12 ? launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 12>(a, p, st) : launch_bwd_weight_reg16<KV_BSPLINE, 9, 3, 4>(a, p, st);
     }
     switch (family) {
         case KANVIT_LINEAR: return launch_bwd_weight_reg<KV_LINEAR, 1, 6>(a, p, bf, st);
         case KANVIT_CHEBY: return p.nt == 1 ? launch_bwd_weight_reg<KV_CHEBY, 5, 1, 5, true, true>(a, p, bf, st) : launch_bwd_weight_reg<KV_CHEBY, 5, 3, 5, true, true>(a, p, bf, st);
         case KANVIT_BSPLINE:      // two windows of five basis slots (exact fp32 when the 16-row kernel does not apply; bf16 mode)
-            return p.nt == 3 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 3, 5, true, true>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 5, true>(a, p, bf, st);
+            return p.nt == 3 ? launch_bwd_weight_reg<KV_BSPLINE, 9, 3, 5, true>(a, p, bf, st) : launch_bwd_weight_reg<KV_BSPLINE, 9, 2, 5, true>(a, p, bf, st);
         case KANVIT_RBF: return launch_bwd_weight_reg<KV_RBF, 9, 2>(a, p, bf, st);
         case KANVIT_SINE:
             if (a.flags & KANVIT_FLAG_SINE_DFREQ) {      // the x * cos operand (d loss / d freq through a weight-gradient pass; kanvit.h)
@@ -561,8 +596,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // MFMAs per basis evaluation), a window evaluating only its own values (compile-time window start).  The idle slot
     // costs 10 % of the MFMAs; 3 x 6 tiles (no idle slot, 288 accumulators) and round 2's 9 x 2 both spill accumulators
     // inside the token loop (the allocator cannot place more than 256 of them) and lose to the LDS-tile kernel.
-    // (bf16 mode runs the same two-window schedule on v_mfma_f32_32x32x16_bf16; the LDS-tile bf16 kernel it replaces there was slower
-    // than the exact 16-row kernel: 0.76 vs 0.70 ms on the ViT-B q|k|v launch)
+    // (bf16 mode runs the same two-window schedule on v_mfma_f32_32x32x16_bf16, see below)
     else if (fam == KANVIT_BSPLINE && p.gp == 9 && (d->flags & KANVIT_FLAG_UNIFORM_KNOTS) && d->spline_order == 3 && d->has_base &&
              !((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16 && kv_config().bs_bw_bf16 == 1)) { p.nt = 3; p.njc = 2; }
     else if (fam == KANVIT_RBF && p.gp == 9 && d->has_base && kv_rbf_reg_ok(d->flags, d->G)) p.nt = 2;      // (windows of 3 measured slower for both: the basis is re-evaluated per window)
@@ -579,7 +613,10 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // FastKAN (exact fp32): the same kernel with all nine values x 4 column tiles of 16 per wave (its q, k, v do not share u):
     // 36 MFMAs per evaluation of the eight Gaussians + silu instead of 18
     bool bf16_mode = (d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16;
-    if (fam == KANVIT_BSPLINE && bf16_mode && kv_config().bs_bw_bf16 != 3) bf16_mode = false;       // B-splines under the bf16 flag: the exact 16-row kernel (the flag allows, never requires, bf16 products)
+    // B-splines under the bf16 flag: the two-window 32-row kernel on the bf16 matrix cores (measured at ViT-B: q|k|v 0.26 ms against 0.70
+    // for the exact 16-row kernel and 0.75 for the LDS-tile bf16 kernel, the patch embedding 1.13 / 3.0 / 3.8 ms; efficient-KAN bf16 step
+    // 39.4 -> 30.7 ms).  KANVIT_BSPLINE_BW_BF16 = 2 keeps the exact kernel under the flag, = 1 the LDS-tile bf16 kernel (A/B).
+    if (fam == KANVIT_BSPLINE && bf16_mode && kv_config().bs_bw_bf16 == 2) bf16_mode = false;
     p.bf = bf16_mode ? 1 : 0;
     if (((fam == KANVIT_BSPLINE && p.njc == 2) || fam == KANVIT_RBF) && !bf16_mode && !kv_config().bw_no_t16) {
         const int sh = (kv_share_ok(fam, d->flags) && nshare > 1) ? 1 : 0;
@@ -662,12 +699,14 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
 int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) { return dispatch_bwd_weight_reg(family, a, p, bf, st); }
 
 // the plans whose kernels exist in the patch-gather form (dispatch_bwd_weight_reg's HAS_PG instantiations): the patch-embedding
-// layers VisionTransformer builds (model.py:67-80: ChebyKAN degree 4, efficient-KAN, SineKAN / FourierKAN at grid 28)
+// layers VisionTransformer builds (model.py:67-80: ChebyKAN degree 4, SineKAN / FourierKAN at grid 28)
 bool kv_bwd_weight_reg_pg_ok(const kanvit_layer_desc* d, const BwRegPlan& p) {
     if (!p.ok || d->groups != 1) return false;
-    if (p.t16) return d->family == KANVIT_BSPLINE;
+    // B-splines are NOT among them: their kernels are at the register limit, and the walker's scalar state spilled (19 scalar registers
+    // in the 16-row kernel, 16 vector registers in the 32-row one): 2.97 against 2.80 ms for the ViT-B patch embedding, 1.82 against
+    // 1.13 ms in bf16 mode -- more than the patch-matrix copy costs.  efficient-KAN's patch embedding keeps the transient patch matrix.
+    if (p.t16) return false;
     switch (d->family) {
-        case KANVIT_BSPLINE: return p.nt == 3;
         case KANVIT_CHEBY: return p.gp == 5 && (p.nt == 3 || p.nt == 1);
         case KANVIT_SINE: return p.gp == 28;
         case KANVIT_FOURIER: return p.gp == 56;

@@ -55,7 +55,7 @@ struct KvConfig {
     int attn_grid;       // KANVIT_ATTN_GRID       work-groups of the persistent attention kernels (tuning; 0 = one round of resident ones)
     int bf16_nsh;        // KANVIT_BF16_NSH        LDS-tile bf16 forward: groups per basis tile (tuning)
     int bf16_ic;         // KANVIT_BF16_IC         LDS-tile bf16 forward: feature chunk cap (tuning)
-    int bs_bw_bf16;      // KANVIT_BSPLINE_BW_BF16 B-spline weight gradient in bf16 mode: 0 = default, 1 = LDS-tile bf16 kernel, 2 = exact 16-row kernel, 3 = 32-row bf16 register kernel
+    int bs_bw_bf16;      // KANVIT_BSPLINE_BW_BF16 B-spline weight gradient in bf16 mode: 0 = default (32-row bf16 register kernel), 1 = LDS-tile bf16 kernel, 2 = exact 16-row kernel (A/B)
     char text[416];
 };
 const KvConfig& kv_config();

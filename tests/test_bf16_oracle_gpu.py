@@ -84,9 +84,7 @@ def test_qkv_bf16_against_rounded_and_exact_oracle(fam, geom):
     # flag (include/kanvit.h: the flag allows bf16 products, exact ones are always valid; the bf16 tile kernel is slower there):
     # those two must match one of the two specified arithmetics
     exact_ok = fam == "sine"
-    # efficient-KAN's WEIGHT gradient likewise: under the bf16 flag it runs the exact 16-row register kernel, which is faster than
-    # both bf16 forms of that contraction -- either specified arithmetic is accepted for its parameters
-    exact_w_ok = fam == "efficientkan"
+    exact_w_ok = False
     err = min(maxrel(xg.grad, gx_t), maxrel(xg.grad, gx_e)) if exact_ok else maxrel(xg.grad, gx_t)
     assert err < TIGHT, (fam, geom, "dx", err)
     for k, g in gp_t.items():
@@ -133,8 +131,7 @@ def test_patch_embedding_layer_bf16(fam, i, o, big):
     assert min(maxrel(xg.grad, gx_t), maxrel(xg.grad, gx_e)) < TIGHT, (fam, "dx", maxrel(xg.grad, gx_t), maxrel(xg.grad, gx_e))
     for k, g in gp_t.items():
         # FastKAN's layernorm.* gradients are column sums of du, i.e. products of the INPUT-gradient kernel: same rule as dx
-        # efficient-KAN's weight gradient runs the exact 16-row kernel under the flag (see the q|k|v test above): same rule
-        err = min(maxrel(got[k], g), maxrel(got[k], gp_e[k])) if (k.startswith("layernorm.") or fam == "efficientkan") else maxrel(got[k], g)
+        err = min(maxrel(got[k], g), maxrel(got[k], gp_e[k])) if k.startswith("layernorm.") else maxrel(got[k], g)
         assert err < TIGHT, (fam, k, err)
     assert 1e-5 < fro(y, y_e) < LOOSE, (fam, fro(y, y_e))
     assert fro(xg.grad, gx_e) < LOOSE, (fam, "dx", fro(xg.grad, gx_e))

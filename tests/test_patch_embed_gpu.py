@@ -64,7 +64,9 @@ def test_fused_patch_embedding_equals_three_step_path_and_oracle(t, geom):
         res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
     assert set(res[0][1]) == set(res[1][1])
     if b * npatch * npatch >= 256 and (chw[0] * (chw[1] // npatch) * (chw[2] // npatch)) % 32 == 0:
-        assert _gathered_backward(m, chw, npatch, d, b)        # the fused backward of these launches gathered (no patch matrix)
+        # the fused backward of these launches gathered (no patch matrix) -- except efficient-KAN, whose weight-gradient kernels
+        # have no register left for the row walker (kan_bwd_weight_reg.hip::kv_bwd_weight_reg_pg_ok)
+        assert _gathered_backward(m, chw, npatch, d, b) == (t != "efficientkan")
     if (chw[2] // npatch) % 8 == 0:
         # both paths run the same kernel instantiation (8-feature chunks): same operations in the same order -> bitwise equal
         assert torch.equal(res[0][0], res[1][0])
