@@ -696,6 +696,9 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     return p;
 }
 
+// (Measured and removed, round 3: an XCD-aware order of the work-groups -- every XCD one contiguous range of the (slab, unit) order, so
+// that waves sharing a dY tile or an x feature block meet in one L2 -- changed no weight-gradient launch by more than the run-to-run
+// noise (ChebyKAN / B-spline / FastKAN / SineKAN G = 28, fp32 and bf16): these kernels wait on their prefetch depth, not on L2 misses.)
 int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) { return dispatch_bwd_weight_reg(family, a, p, bf, st); }
 
 // the plans whose kernels exist in the patch-gather form (dispatch_bwd_weight_reg's HAS_PG instantiations): the patch-embedding
