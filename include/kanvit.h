@@ -243,7 +243,9 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
  * key and the reference's answer depends on its bucket sizes -- KANVIT_EINVAL here.  d as for kanvit_attn_fwd with
  * d->N = q_len (q, o, do, dq: [B][H][q_len][D] through the q / o strides; k, v, dk, dv: [B][H][Nk][D] through the k / v
  * strides; lse [B][H][q_len]).  Exact fp32 (KANVIT_FLAG_BF16_MFMA is refused).  A query whose keys are all dead gets o = 0,
- * lse = -FLT_MAX, zero gradients.  The swept operand of a head must fit the LDS: q_len, k_len <= 224 (256 for D <= 32). */
+ * lse = -FLT_MAX, zero gradients.  Any q_len / k_len: the swept operand is walked in LDS chunks of 128 rows (running max / sum in
+ * the forward, utils.py:199-221), so these entry points also serve self-attention heads too long for kanvit_attn_fwd's
+ * one-head-per-work-group form (N > 224 at D = 64). */
 typedef struct kanvit_attn_ext {
     int32_t Nk;              /* key / value length */
     int32_t reserved;

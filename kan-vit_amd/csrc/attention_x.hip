@@ -7,17 +7,18 @@
 // query i sees keys j <= i - (k_len - q_len)), the first k_len - q_len queries have no visible key and its answer for them depends
 // on the bucket sizes -- refused here (KANVIT_EINVAL) instead of imitated.  The ViT path never uses either (attention.hip's kernels: one length, no
 // mask); these kernels cover the rest of the function's domain with the same tile orientation as attention.hip's first form:
-//   forward       work-group = one (batch, head): K, V images [NKP][KS] in LDS, a wave owns a 32-query tile,
-//                 S^T = K.Q^T with the key index in the accumulator register index -> exact softmax in registers (no online
-//                 rescale: all <= 8 key tiles of a strip are live) -> O^T = V^T.P^T from registers
-//   backward      rowsum(dO*O) (attn_x_delta_kernel), then a key-stationary kernel (Q, dO images in LDS; dK^T, dV^T in
-//                 accumulators) and a query-stationary one (K, V images in LDS; dQ^T in accumulators): no atomics, bitwise
-//                 reproducible
+//   forward       work-group = four 32-query tiles of one (batch, head), one per wave; the keys are swept in LDS chunks of 128 rows
+//                 (K, V images [128][KS]); S^T = K.Q^T with the key index in the accumulator register index -> softmax over the
+//                 chunk in registers, running (max, sum) across chunks (utils.py:199-221) -> O^T = V^T.P^T from registers
+//   backward      rowsum(dO*O) (attn_x_delta_kernel), then a key-stationary kernel (a wave owns a key tile: dK^T, dV^T in
+//                 accumulators; Q, dO swept in LDS chunks) and a query-stationary one (dQ^T in accumulators; K, V swept in
+//                 chunks): no atomics, bitwise reproducible
+// ANY sequence length (the swept operand never has to fit the LDS): ops.attention also routes self-attention heads that do not fit
+// the ViT kernels of attention.hip (N > 224 at D = 64, e.g. ViT-B/16 at 384 x 384: N = 577) here.
 // A position is dead when key >= k_len, or causal and key > query, or the mask says so.  A query whose keys are ALL
 // dead gets o = 0, lse = -FLT_MAX and zero gradients (the reference's clamp(min=EPSILON) row sum gives the same o = 0 and
 // lse = log(1e-10) - FLT_MAX for a fully MASKED row).
-// Limits (host-checked): D even and <= 64; the swept operand of a head must fit the LDS: k_len (forward, dQ) and q_len (dK, dV)
-// <= 224 at D > 32, <= 256 at D <= 32.
+// Limits (host-checked): D even and <= 64.
 #include "kanvit_common.h"
 
 #include <float.h>
@@ -97,16 +98,21 @@ __device__ __forceinline__ void x_store_tile(float* __restrict__ dstg, long long
     }
 }
 
-template <int DT, int NKT>
+constexpr int XCH = 4;            // tiles of 32 rows per LDS chunk of the swept operand (128 rows)
+
+// forward: grid (B*H, ceil(q tiles / 4)); a wave owns a 32-query tile and sweeps the keys in chunks of XCH tiles with the running
+// (max, sum) rescale of utils.py:199-221 -- in this orientation (O^T[d][query]: the query is the lane) the rescale of the partial
+// output is one multiplication of the lane's accumulators by a lane-private factor
+template <int DT>
 __global__ __launch_bounds__(XTHR) void attn_x_fwd_kernel(const AttnXArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KS = 32 * DT + 1;
+    constexpr int KS = 32 * DT + 1, CH = XCH * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
-    const int D = a.D, nkt = a.nkt, NKP = nkt * 32;
+    const int D = a.D, nkt = a.nkt;
     float* K_s = smem;
-    float* V_s = K_s + NKP * KS;
-    float* Q_w = V_s + NKP * KS + wave * 32 * KS;
+    float* V_s = K_s + CH * KS;
+    float* Q_w = V_s + CH * KS + wave * 32 * KS;
 
     const float* qb = a.q + bi * a.qsb + hi * a.qsh;
     const float* kb = a.k + bi * a.ksb + hi * a.ksh;
@@ -114,91 +120,90 @@ __global__ __launch_bounds__(XTHR) void attn_x_fwd_kernel(const AttnXArgs a) {
     float* ob = a.out + bi * a.osb + hi * a.osh;
     const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
 
-    x_load_tile<DT>(K_s, kb, a.ksn, 0, NKP, a.Nk, D, tid, XTHR);
-    x_load_tile<DT>(V_s, vb, a.vsn, 0, NKP, a.Nk, D, tid, XTHR);
-
     const float sc2 = a.scale * LOG2E_X;
-    const int niter = (a.nqt + 3) / 4;
-    for (int it = 0; it < niter; ++it) {
-        const int qt = it * 4 + wave;            // tiles past nqt run on zero rows and store nothing
-        x_load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
-        __syncthreads();
-        float qf[16 * DT];
+    const int qt = blockIdx.y * 4 + wave;        // tiles past nqt run on zero rows and store nothing
+    const int qrow = qt * 32 + l31;
+    x_load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+    __syncthreads();
+    float qf[16 * DT];
 #pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) qf[s] = Q_w[l31 * KS + 2 * s + hf];
+    for (int s = 0; s < 16 * DT; ++s) qf[s] = Q_w[l31 * KS + 2 * s + hf];
 
-        f32x16 sacc[NKT];
+    f32x16 oacc[DT];
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) {
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+    float mrun = -INFINITY, lrun = 0.0f;         // running max (raw scores) and sum of this lane's query
+
+    for (int kc = 0; kc < nkt; kc += XCH) {
+        __syncthreads();                         // every wave is done with the previous chunk
+        x_load_tile<DT>(K_s, kb, a.ksn, kc * 32, CH, a.Nk, D, tid, XTHR);
+        x_load_tile<DT>(V_s, vb, a.vsn, kc * 32, CH, a.Nk, D, tid, XTHR);
+        __syncthreads();
+        f32x16 sacc[XCH];
+        unsigned dbits[XCH];
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[j][r] = 0.0f;
-            if (j < nkt) {
+            dbits[j] = (kc + j < nkt) ? x_dead_bits<true>(a, mb, qrow, (kc + j) * 32, hf) : 0xffffu;
+            if (kc + j < nkt) {
                 const float* kp = K_s + (j * 32 + l31) * KS + hf;
 #pragma unroll
                 for (int s = 0; s < 16 * DT; ++s) sacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc[j], 0, 0, 0);
             }
         }
-        const int qrow = qt * 32 + l31;
-        unsigned dbits[NKT];
+        float mx = mrun;
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) dbits[j] = (j < nkt) ? x_dead_bits<true>(a, mb, qrow, j * 32, hf) : 0xffffu;
-        float mx = -INFINITY;
+        for (int j = 0; j < XCH; ++j)
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) {
-            if (j < nkt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sv = ((dbits[j] >> r) & 1u) ? -INFINITY : sacc[j][r];
-                    sacc[j][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float sv = ((dbits[j] >> r) & 1u) ? -INFINITY : sacc[j][r];
+                sacc[j][r] = sv;
+                mx = fmaxf(mx, sv);
             }
-        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mxs = (mx == -INFINITY) ? 0.0f : mx * sc2;
+        const float corr = exp2f(mrun * sc2 - mxs);          // 0 while nothing was live before (mrun = -inf)
         float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) {
-            if (j < nkt) {
+        for (int j = 0; j < XCH; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(sacc[j][r] * sc2 - mxs);
-                    sacc[j][r] = p;
-                    sum += p;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(sacc[j][r] * sc2 - mxs);
+                sacc[j][r] = p;
+                sum += p;
             }
-        }
         sum += __shfl_xor(sum, 32);
-        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;          // every key dead: o = 0
-
-        f32x16 oacc[DT];
+        lrun = lrun * corr + sum;
+        mrun = mx;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= corr;
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) {
-            if (j < nkt) {
+        for (int j = 0; j < XCH; ++j) {
+            if (kc + j < nkt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = sacc[j][r] * inv;
                     const float* vp = V_s + (j * 32 + kv_acc_row(r, hf)) * KS + l31;
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], pv, oacc[dt], 0, 0, 0);
+                    for (int dt = 0; dt < DT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], sacc[j][r], oacc[dt], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
+    }
+    const float inv = lrun > 0.0f ? 1.0f / lrun : 0.0f;      // every key dead: o = 0
+    __syncthreads();
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Q_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = oacc[dt][r];
-        __syncthreads();
-        if (qt < a.nqt) {
-            x_store_tile<DT>(ob, a.osn, qt * 32, a.Nq, D, Q_w, lane);
-            if (hf == 0 && qrow < a.Nq && a.lse) a.lse[(long long)bh * a.Nq + qrow] = sum > 0.0f ? mx * a.scale + logf(sum) : -FLT_MAX;
-        }
-        __syncthreads();
+        for (int r = 0; r < 16; ++r) Q_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = oacc[dt][r] * inv;
+    __syncthreads();
+    if (qt < a.nqt) {
+        x_store_tile<DT>(ob, a.osn, qt * 32, a.Nq, D, Q_w, lane);
+        if (hf == 0 && qrow < a.Nq && a.lse) a.lse[(long long)bh * a.Nq + qrow] = lrun > 0.0f ? mrun * a.scale + logf(lrun) : -FLT_MAX;
     }
 }
 
@@ -223,19 +228,20 @@ __global__ __launch_bounds__(256) void attn_x_delta_kernel(const AttnXArgs a) {
     if (row < rows && sub == 0) a.delta[row] = s;
 }
 
-// dK, dV: key-stationary (a wave owns a 32-key tile and sweeps the query tiles; utils.py:262-291)
+// dK, dV: key-stationary (utils.py:262-291).  grid (B*H, ceil(key tiles / 4)); a wave owns a 32-key tile (K, V fragments in registers,
+// dK^T / dV^T in accumulators) and sweeps the queries in LDS chunks of XCH tiles.
 template <int DT>
 __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KS = 32 * DT + 1;
+    constexpr int KS = 32 * DT + 1, CH = XCH * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
-    const int D = a.D, NQP = a.nqt * 32;
+    const int D = a.D;
     float* Q_s = smem;
-    float* dO_s = Q_s + NQP * KS;
-    float* lse_s = dO_s + NQP * KS;
-    float* dl_s = lse_s + NQP;
-    float* T_w = dl_s + NQP + wave * 32 * KS;
+    float* dO_s = Q_s + CH * KS;
+    float* lse_s = dO_s + CH * KS;
+    float* dl_s = lse_s + CH;
+    float* T_w = dl_s + CH + wave * 32 * KS;
 
     const float* qb = a.q + bi * a.qsb + hi * a.qsh;
     const float* kb = a.k + bi * a.ksb + hi * a.ksh;
@@ -244,64 +250,65 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) 
     float* dkb = a.dk + bi * a.ksb + hi * a.ksh;
     float* dvb = a.dv + bi * a.vsb + hi * a.vsh;
     const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
-
-    x_load_tile<DT>(Q_s, qb, a.qsn, 0, NQP, a.Nq, D, tid, XTHR);
-    x_load_tile<DT>(dO_s, dob, a.osn, 0, NQP, a.Nq, D, tid, XTHR);
-    for (int n = tid; n < NQP; n += XTHR) {
-        lse_s[n] = (n < a.Nq) ? a.lse_in[(long long)bh * a.Nq + n] * LOG2E_X : INFINITY;
-        dl_s[n] = (n < a.Nq) ? a.delta_in[(long long)bh * a.Nq + n] : 0.0f;
-    }
     const float sc2 = a.scale * LOG2E_X;
-    const int niter = (a.nkt + 3) / 4;
-    for (int it = 0; it < niter; ++it) {
-        const int jt = it * 4 + wave;
-        const int key = jt * 32 + l31;
-        float kf[16 * DT], vf[16 * DT];
-        x_load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
-        __syncthreads();
-        x_load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
 
-        f32x16 dkacc[DT], dvacc[DT];
+    const int jt = blockIdx.y * 4 + wave;
+    const int key = jt * 32 + l31;
+    float kf[16 * DT], vf[16 * DT];
+    x_load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
+    __syncthreads();
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
+    __syncthreads();
+    x_load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
+    __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dkacc[dt][r] = 0.0f;
-                dvacc[dt][r] = 0.0f;
-            }
-        for (int qt = 0; qt < a.nqt; ++qt) {
+    for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
+
+    f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dkacc[dt][r] = 0.0f;
+            dvacc[dt][r] = 0.0f;
+        }
+    for (int qc = 0; qc < a.nqt; qc += XCH) {
+        __syncthreads();
+        x_load_tile<DT>(Q_s, qb, a.qsn, qc * 32, CH, a.Nq, D, tid, XTHR);
+        x_load_tile<DT>(dO_s, dob, a.osn, qc * 32, CH, a.Nq, D, tid, XTHR);
+        for (int n = tid; n < CH; n += XTHR) {
+            const int qn = qc * 32 + n;
+            lse_s[n] = (qn < a.Nq) ? a.lse_in[(long long)bh * a.Nq + qn] * LOG2E_X : INFINITY;      // exp2(-inf) = 0 on pad rows
+            dl_s[n] = (qn < a.Nq) ? a.delta_in[(long long)bh * a.Nq + qn] : 0.0f;
+        }
+        __syncthreads();
+        for (int qq = 0; qq < XCH && qc + qq < a.nqt; ++qq) {
             f32x16 sacc, pacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 sacc[r] = 0.0f;
                 pacc[r] = 0.0f;
             }
-            const float* qp = Q_s + (qt * 32 + l31) * KS + hf;
-            const float* dp = dO_s + (qt * 32 + l31) * KS + hf;
+            const float* qp = Q_s + (qq * 32 + l31) * KS + hf;
+            const float* dp = dO_s + (qq * 32 + l31) * KS + hf;
 #pragma unroll
             for (int s = 0; s < 16 * DT; ++s) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[2 * s], kf[s], sacc, 0, 0, 0);      // S[q][key]
                 pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[2 * s], vf[s], pacc, 0, 0, 0);      // dP[q][key]
             }
-            const unsigned db = x_dead_bits<false>(a, mb, key, qt * 32, hf);
+            const unsigned db = x_dead_bits<false>(a, mb, key, (qc + qq) * 32, hf);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qrow = qt * 32 + kv_acc_row(r, hf);
-                float p = exp2f(sacc[r] * sc2 - lse_s[qrow]);
+                const int ql = qq * 32 + kv_acc_row(r, hf), qrow = qc * 32 + ql;
+                float p = exp2f(sacc[r] * sc2 - lse_s[ql]);
                 if (jt >= a.nkt || qrow >= a.Nq || ((db >> r) & 1u)) p = 0.0f;          // select, never multiply: exp2 may be inf on a dead row
                 sacc[r] = p;
-                pacc[r] = p * a.scale * (pacc[r] - dl_s[qrow]);
-                if (p == 0.0f) pacc[r] = 0.0f;
+                pacc[r] = p == 0.0f ? 0.0f : p * a.scale * (pacc[r] - dl_s[ql]);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (qt * 32 + kv_acc_row(r, hf)) * KS + l31;
+                const int row = (qq * 32 + kv_acc_row(r, hf)) * KS + l31;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dO_s[row + dt * 32], sacc[r], dvacc[dt], 0, 0, 0);
@@ -309,35 +316,34 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) 
                 }
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dkacc[dt][r];
-        __syncthreads();
-        if (jt < a.nkt) x_store_tile<DT>(dkb, a.ksn, jt * 32, a.Nk, D, T_w, lane);
-        __syncthreads();
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dvacc[dt][r];
-        __syncthreads();
-        if (jt < a.nkt) x_store_tile<DT>(dvb, a.vsn, jt * 32, a.Nk, D, T_w, lane);
-        __syncthreads();
     }
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dkacc[dt][r];
+    __syncthreads();
+    if (jt < a.nkt) x_store_tile<DT>(dkb, a.ksn, jt * 32, a.Nk, D, T_w, lane);
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dvacc[dt][r];
+    __syncthreads();
+    if (jt < a.nkt) x_store_tile<DT>(dvb, a.vsn, jt * 32, a.Nk, D, T_w, lane);
 }
 
-// dQ: query-stationary mirror of the forward kernel
+// dQ: query-stationary mirror of the forward kernel (grid (B*H, ceil(q tiles / 4)); keys swept in LDS chunks of XCH tiles)
 template <int DT>
 __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KS = 32 * DT + 1;
+    constexpr int KS = 32 * DT + 1, CH = XCH * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.x, bi = bh / a.H, hi = bh - bi * a.H;
-    const int D = a.D, nkt = a.nkt, NKP = nkt * 32;
+    const int D = a.D, nkt = a.nkt;
     float* K_s = smem;
-    float* V_s = K_s + NKP * KS;
-    float* T_w = V_s + NKP * KS + wave * 32 * KS;
+    float* V_s = K_s + CH * KS;
+    float* T_w = V_s + CH * KS + wave * 32 * KS;
 
     const float* qb = a.q + bi * a.qsb + hi * a.qsh;
     const float* kb = a.k + bi * a.ksb + hi * a.ksh;
@@ -345,34 +351,35 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
     const float* dob = a.d_o + bi * a.osb + hi * a.osh;
     float* dqb = a.dq + bi * a.qsb + hi * a.qsh;
     const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
-
-    x_load_tile<DT>(K_s, kb, a.ksn, 0, NKP, a.Nk, D, tid, XTHR);
-    x_load_tile<DT>(V_s, vb, a.vsn, 0, NKP, a.Nk, D, tid, XTHR);
     const float sc2 = a.scale * LOG2E_X;
-    const int niter = (a.nqt + 3) / 4;
-    for (int it = 0; it < niter; ++it) {
-        const int qt = it * 4 + wave;
-        const int qrow = qt * 32 + l31;
-        const bool q_ok = (qt < a.nqt) && (qrow < a.Nq);
-        float qf[16 * DT], dof[16 * DT];
-        x_load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
-        __syncthreads();
-        x_load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
-        const float lse2 = q_ok ? a.lse_in[(long long)bh * a.Nq + qrow] * LOG2E_X : INFINITY;
-        const float dl = q_ok ? a.delta_in[(long long)bh * a.Nq + qrow] : 0.0f;
 
-        f32x16 dqacc[DT];
+    const int qt = blockIdx.y * 4 + wave;
+    const int qrow = qt * 32 + l31;
+    const bool q_ok = (qt < a.nqt) && (qrow < a.Nq);
+    float qf[16 * DT], dof[16 * DT];
+    x_load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+    __syncthreads();
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
+    __syncthreads();
+    x_load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+    __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
-        for (int j = 0; j < nkt; ++j) {
+    for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
+    const float lse2 = q_ok ? a.lse_in[(long long)bh * a.Nq + qrow] * LOG2E_X : INFINITY;
+    const float dl = q_ok ? a.delta_in[(long long)bh * a.Nq + qrow] : 0.0f;
+
+    f32x16 dqacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
+    for (int kc = 0; kc < nkt; kc += XCH) {
+        __syncthreads();
+        x_load_tile<DT>(K_s, kb, a.ksn, kc * 32, CH, a.Nk, D, tid, XTHR);
+        x_load_tile<DT>(V_s, vb, a.vsn, kc * 32, CH, a.Nk, D, tid, XTHR);
+        __syncthreads();
+        for (int j = 0; j < XCH && kc + j < nkt; ++j) {
             f32x16 sacc, pacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qf[s], sacc, 0, 0, 0);      // S^T[key][q]
                 pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * s], dof[s], pacc, 0, 0, 0);     // dP^T[key][q]
             }
-            const unsigned db = x_dead_bits<true>(a, mb, qrow, j * 32, hf);
+            const unsigned db = x_dead_bits<true>(a, mb, qrow, (kc + j) * 32, hf);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = exp2f(sacc[r] * sc2 - lse2);
@@ -400,15 +407,14 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
                 for (int dt = 0; dt < DT; ++dt) dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[dt * 32], pacc[r], dqacc[dt], 0, 0, 0);
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dqacc[dt][r];
-        __syncthreads();
-        if (qt < a.nqt) x_store_tile<DT>(dqb, a.qsn, qt * 32, a.Nq, D, T_w, lane);
-        __syncthreads();
     }
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T_w[l31 * KS + dt * 32 + kv_acc_row(r, hf)] = dqacc[dt][r];
+    __syncthreads();
+    if (qt < a.nqt) x_store_tile<DT>(dqb, a.qsn, qt * 32, a.Nq, D, T_w, lane);
 }
 
 int x_check(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const char* who) {
@@ -419,12 +425,7 @@ int x_check(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const char* who
     if (d->causal && e->Nk > d->N)
         return kv_fail(KANVIT_EINVAL, "%s: causal with k_len=%d > q_len=%d is ill-defined in the reference (utils.py:169,183: the first k_len - q_len queries see no key)", who, e->Nk, d->N);
     if (d->flags & KANVIT_FLAG_BF16_MFMA) return kv_fail(KANVIT_EINVAL, "%s: the general attention kernels are exact fp32 (no KANVIT_FLAG_BF16_MFMA)", who);
-    const int ks = (d->D <= 32 ? 32 : 64) + 1;
-    const int nmax = d->N > e->Nk ? d->N : e->Nk, np = (nmax + 31) / 32 * 32;
-    const size_t lds = sizeof(float) * ((size_t)2 * np * ks + 2 * (size_t)np + (size_t)4 * 32 * ks);
-    if (np > 256 || lds > 160 * 1024)
-        return kv_fail(KANVIT_EINVAL, "%s: q_len=%d, k_len=%d with D=%d: the swept operand of a head must fit a CU's LDS (%zu bytes > 160 KiB)", who,
-                       d->N, e->Nk, d->D, lds);
+    if ((long long)(d->N + 127) / 128 > 65535 || (long long)(e->Nk + 127) / 128 > 65535) return kv_fail(KANVIT_EINVAL, "%s: sequence too long for one launch", who);
     return 0;
 }
 
@@ -444,34 +445,24 @@ AttnXArgs x_args(const kanvit_attn_desc* d, const kanvit_attn_ext* e) {
 
 template <int DT>
 int x_launch_fwd(const AttnXArgs& a, hipStream_t st) {
-    constexpr int KS = 32 * DT + 1;
-    const size_t lds = sizeof(float) * ((size_t)2 * a.nkt * 32 * KS + (size_t)4 * 32 * KS);
-    const dim3 grid((unsigned)(a.B * a.H));
-    if (a.nkt <= 2) {
-        KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT, 2>));
-        hipLaunchKernelGGL((attn_x_fwd_kernel<DT, 2>), grid, dim3(XTHR), lds, st, a);
-    } else if (a.nkt <= 4) {
-        KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT, 4>));
-        hipLaunchKernelGGL((attn_x_fwd_kernel<DT, 4>), grid, dim3(XTHR), lds, st, a);
-    } else {
-        KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT, 8>));
-        hipLaunchKernelGGL((attn_x_fwd_kernel<DT, 8>), grid, dim3(XTHR), lds, st, a);
-    }
+    constexpr int KS = 32 * DT + 1, CH = XCH * 32;
+    const size_t lds = sizeof(float) * ((size_t)2 * CH * KS + (size_t)4 * 32 * KS);
+    KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT>));
+    hipLaunchKernelGGL((attn_x_fwd_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nqt + 3) / 4)), dim3(XTHR), lds, st, a);
     KV_LAUNCH_CHECK("attn_x_fwd_kernel");
     return 0;
 }
 
 template <int DT>
 int x_launch_bwd(const AttnXArgs& a, hipStream_t st) {
-    constexpr int KS = 32 * DT + 1;
-    const size_t lds_kv = sizeof(float) * ((size_t)2 * a.nqt * 32 * KS + 2 * (size_t)a.nqt * 32 + (size_t)4 * 32 * KS);
-    const size_t lds_q = sizeof(float) * ((size_t)2 * a.nkt * 32 * KS + (size_t)4 * 32 * KS);
-    const dim3 grid((unsigned)(a.B * a.H));
+    constexpr int KS = 32 * DT + 1, CH = XCH * 32;
+    const size_t lds_kv = sizeof(float) * ((size_t)2 * CH * KS + 2 * (size_t)CH + (size_t)4 * 32 * KS);
+    const size_t lds_q = sizeof(float) * ((size_t)2 * CH * KS + (size_t)4 * 32 * KS);
     KV_ALLOW_LDS(160 * 1024, (attn_x_bwd_kv_kernel<DT>));
     KV_ALLOW_LDS(160 * 1024, (attn_x_bwd_q_kernel<DT>));
-    hipLaunchKernelGGL((attn_x_bwd_kv_kernel<DT>), grid, dim3(XTHR), lds_kv, st, a);
+    hipLaunchKernelGGL((attn_x_bwd_kv_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nkt + 3) / 4)), dim3(XTHR), lds_kv, st, a);
     KV_LAUNCH_CHECK("attn_x_bwd_kv_kernel");
-    hipLaunchKernelGGL((attn_x_bwd_q_kernel<DT>), grid, dim3(XTHR), lds_q, st, a);
+    hipLaunchKernelGGL((attn_x_bwd_q_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nqt + 3) / 4)), dim3(XTHR), lds_q, st, a);
     KV_LAUNCH_CHECK("attn_x_bwd_q_kernel");
     return 0;
 }

@@ -447,7 +447,16 @@ def _attn_desc(q, k, v, o, causal: bool, scale: float, flags: int = 0) -> AttnDe
                     v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2))
 
 
+def _attn_fits_one_workgroup(N: int, D: int) -> bool:
+    """The ViT kernels of csrc/attention.hip hold one head in a work-group's LDS (check_desc's bound: N <= 224 at D = 64, 256 at
+    D <= 32); longer sequences (e.g. 384 x 384 images at patch 16: N = 577) take the chunked general kernels (csrc/attention_x.hip)."""
+    ks, npad = (32 if D <= 32 else 64) + 1, (N + 31) // 32 * 32
+    return N <= 256 and 4 * (2 * npad * ks + 2 * npad + 4 * 32 * ks) <= 160 * 1024
+
+
 def _attn_fwd(q, k, v, o, causal, scale, flags=0):
+    if q.dim() == 4 and tuple(k.shape) == tuple(q.shape) and not _attn_fits_one_workgroup(q.shape[2], q.shape[3]):
+        return _attn_x_fwd(q, k, v, o, None, causal, scale)
     B, H, N, _ = q.shape
     lse = torch.empty(B, H, N, device=q.device, dtype=torch.float32)
     d = _attn_desc(q, k, v, o, causal, scale, flags)
@@ -459,6 +468,8 @@ def _attn_fwd(q, k, v, o, causal, scale, flags=0):
 
 
 def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal, scale, flags=0):
+    if q.dim() == 4 and tuple(k.shape) == tuple(q.shape) and not _attn_fits_one_workgroup(q.shape[2], q.shape[3]):
+        return _attn_x_bwd(q, k, v, o, lse, do, dq, dk, dv, None, causal, scale)
     d = _attn_desc(q, k, v, o, causal, scale, flags)
     if (do.stride() != o.stride()) or dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != v.stride():
         raise KanvitError("attention backward: gradient layouts must match their forward tensors")

@@ -207,10 +207,6 @@ def test_self_attention_binding_refuses_other_shapes():
         FlashAttentionFunction.apply(q, k, k, None, True, 512, 512)
     with pytest.raises(KanvitError, match="ill-defined"):
         ops._attn_x_fwd(q, k, k, torch.empty_like(q), None, True, 32 ** -0.5)
-    # the swept operand of a head must fit the LDS
-    kl = torch.randn(1, 1, 300, 64, device=DEV)
-    with pytest.raises(KanvitError, match="LDS"):
-        ops._attn_x_fwd(q[:1, :1, :, :].repeat(1, 1, 1, 2).contiguous(), kl, kl, torch.empty(1, 1, 40, 64, device=DEV), None, False, 0.125)
 
 
 FLASH_X_CASES = ["keypad", "cross", "cross_mask4", "short_causal", "keypad_causal"]
@@ -246,11 +242,12 @@ def test_flash_function_fully_masked_sample():
         assert torch.isfinite(t.grad).all() and float(t.grad[1].abs().max()) == 0.0     # nothing flows through the masked sample
 
 
-@pytest.mark.parametrize("nq,nk", [(1, 1), (7, 50), (50, 7), (33, 64), (64, 33), (197, 50), (50, 197), (224, 224), (130, 97)])
+@pytest.mark.parametrize("nq,nk", [(1, 1), (7, 50), (50, 7), (33, 64), (64, 33), (197, 50), (50, 197), (224, 224), (130, 97), (577, 577), (300, 700), (1000, 64)])
 @pytest.mark.parametrize("d", [2, 8, 32, 64])
 @pytest.mark.parametrize("kind", ["none", "keypad", "full", "full_heads", "causal", "causal_keypad"])
 def test_general_attention_against_fp64_oracle(nq, nk, d, kind):
-    """The general kernels over lengths (ragged tiles on both sides, one side longer than the other), head sizes and mask
+    """The general kernels over lengths (ragged tiles on both sides, one side longer than the other, sequences of several 128-row
+    LDS chunks: the running (max, sum) rescale of the forward, accumulators carried across chunks in the backward), head sizes and mask
     layouts -- (b, n) key padding, (b, 1, q, k) and (b, h, q, k) masks, strided (expanded) mask views -- against the float64
     oracle, forward and all three gradients; bitwise run-to-run."""
     from utils import FlashAttentionFunction
@@ -353,3 +350,51 @@ def test_fourth_form_ring_kernels(n, causal, monkeypatch):
         assert close(g, ref)
     for a, c in zip(ring, third):                                        # same mathematics, same summation order per tile
         assert max_err(a, c) < 2e-6 * max(1.0, float(c.abs().max()))
+
+
+@pytest.mark.parametrize("n,d", [(257, 32), (225, 64), (577, 64), (1025, 16)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_self_attention_longer_than_one_workgroup(n, d, causal):
+    """Heads that do not fit the ViT kernels' one-work-group-per-head form (N > 224 at D = 64, > 256 at D <= 32; ViT-B/16 at
+    384 x 384 is N = 577) run through the chunked general kernels: ops.attention and the packed q|k|v form MSA uses, against the
+    float64 oracle."""
+    from kanvit import ops
+    torch.manual_seed(n + d)
+    b, h = 2, 2
+    q, k, v = (torch.randn(b, h, n, d) * 1.2 for _ in range(3))
+    do = torch.randn(b, h, n, d)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = ko.attention_reference(qd, kd, vd, causal=causal)
+    o_ref.backward(do.double())
+    qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    o = ops.attention(qg, kg, vg, causal=causal)
+    o.backward(do.to(DEV))
+    assert max_err(o.cpu(), o_ref) < 1e-5
+    assert close(qg.grad, qd.grad) and close(kg.grad, kd.grad) and close(vg.grad, vd.grad)
+    if not causal:
+        qkv = torch.stack([q, k, v], dim=0).permute(1, 3, 0, 2, 4).contiguous().to(DEV).requires_grad_(True)      # [B, N, 3, H, D]
+        op = ops.attention_packed(qkv)                   # o[B, N, H*D]
+        assert max_err(op.reshape(b, n, h, d).permute(0, 2, 1, 3).cpu(), o_ref) < 1e-5
+
+
+@pytest.mark.parametrize("t", ["vanilla", "cheby"])
+def test_vit_with_more_tokens_than_one_workgroup_holds(t):
+    """A model whose sequence does not fit the one-head-per-work-group attention kernels (32 x 32 images in 2 x 2 patches: N = 257,
+    dh = 32) runs through MSA -> attention_packed -> the chunked general kernels: logits, loss and every gradient against
+    oracle.vit_forward in float64 (the reference handles any length; round 2 raised here)."""
+    from model import VisionTransformer
+    torch.manual_seed(5)
+    m = VisionTransformer((1, 32, 32), n_patches=16, n_blocks=1, d_hidden=64, n_heads=2, out_d=10, type=t).to(DEV)
+    x = torch.rand(3, 1, 32, 32)
+    y = torch.arange(3) % 10
+    logits = m(x.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(DEV))
+    loss.backward()
+    sd = {k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu() for k, v in m.state_dict().items()}
+    params = {k: v.clone().requires_grad_(not ko.is_buffer_key(k)) for k, v in sd.items()}
+    ref = ko.vit_forward(params, x.double(), 16, 2, t)
+    ref_loss = torch.nn.functional.cross_entropy(ref, y)
+    ref_loss.backward()
+    assert max_err(logits.detach().cpu(), ref.detach()) < 1e-4 and abs(float(loss) - float(ref_loss)) < 1e-5
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), params[k].grad) < 1e-4, k

@@ -47,7 +47,7 @@ def _gathered_backward(m, chw, npatch, d, b, bf16=False):
 
 @pytest.mark.parametrize("t", ["cheby", "efficientkan", "sine"])      # (FourierKAN at grid 28: 112 weight rows per 2-feature chunk exceed the fp32 forward's staging registers)
 @pytest.mark.parametrize("geom", [((3, 32, 32), 4, 64, 5), ((3, 224, 224), 14, 768, 2), ((1, 64, 64), 4, 128, 3), ((1, 28, 28), 7, 64, 6),
-                                  ((3, 32, 32), 4, 64, 21), ((1, 64, 64), 4, 128, 37)])
+                                  ((3, 32, 32), 4, 64, 21), ((1, 64, 64), 4, 128, 37), ((3, 32, 64), 4, 64, 21)])      # last: non-square images
 def test_fused_patch_embedding_equals_three_step_path_and_oracle(t, geom):
     from model import VisionTransformer
     chw, npatch, d, b = geom
@@ -160,3 +160,34 @@ def test_patch_embed_bwd_weight_entry_point_rejects_what_it_does_not_cover():
     assert rc != 0 and b"not covered" in L.kanvit_last_error()
     rc = L.kanvit_patch_embed_bwd_weight(C.byref(d), C.byref(pd), ops._ptr(x), None, ops._ptr(dy), ops._ptr(dw), None, 0, None)
     assert rc != 0 and b"workspace" in L.kanvit_last_error()
+
+
+@pytest.mark.parametrize("pre", [0, 1])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_patch_embed_bwd_weight_through_the_c_abi(pre, bf16):
+    """kanvit_patch_embed_bwd_weight called directly, with and without class-token rows in dY (prepend_rows = 0 is not reachable
+    through the model), on a batch whose slabs end inside an image: bitwise equal to kanvit_layer_bwd_weight on the patch matrix."""
+    import ctypes as C
+    from kanvit import _lib, ops
+    L = _lib.lib()
+    torch.manual_seed(4 + pre)
+    B, Cc, H, W, n, O = 23, 3, 64, 32, 4, 96
+    P, I = n * n, Cc * (H // n) * (W // n)
+    cfg = ops.LayerCfg(_lib.CHEBY, I, O, 5, flags=_lib.FLAG_BF16_MFMA if bf16 else 0)
+    images = torch.randn(B, Cc, H, W, device=DEV)
+    dy = torch.randn(B, P + pre, O, device=DEV)
+    d = ops._desc(cfg, B * P, I, I, O, 0)
+    pd = _lib.PatchDesc(Cc, H, W, n, pre, 0)
+    assert L.kanvit_patch_embed_bwd_weight_ok(C.byref(d), C.byref(pd)) == 1
+    nb = int(L.kanvit_patch_embed_bwd_weight_workspace(C.byref(d), C.byref(pd)))
+    ws = torch.empty(max(nb // 4, 1), device=DEV)
+    dw = torch.full((1, I * 5, O), float("nan"), device=DEV)
+    ops.check(L.kanvit_patch_embed_bwd_weight(C.byref(d), C.byref(pd), ops._ptr(images), None, ops._ptr(dy), ops._ptr(dw), ops._ptr(ws), C.c_size_t(nb), None), "bwd_weight")
+    x = ops.patchify(images, n).reshape(-1, I).contiguous()
+    dyt = dy[:, pre:, :].reshape(-1, O).contiguous()
+    nb2 = int(L.kanvit_layer_bwd_weight_workspace(C.byref(d)))
+    ws2 = torch.empty(max(nb2 // 4, 1), device=DEV)
+    dw2 = torch.empty_like(dw)
+    ops.check(L.kanvit_layer_bwd_weight(C.byref(d), ops._ptr(x), None, None, ops._ptr(dyt), ops._ptr(dw2), ops._ptr(ws2), C.c_size_t(nb2), None), "layer_bwd_weight")
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all() and torch.equal(dw, dw2)        # (the patch-matrix kernel itself is checked against the fp64 oracle in test_layers_gpu.py)
