@@ -318,9 +318,13 @@ int try_fwd_reg(const LayerArgs& a, hipStream_t st) {
     // (Measured and rejected, round 3: EIGHT column tiles per generated value for SineKAN's G = 28 patch embedding -- it halves the
     // sine evaluations per MFMA, 5.5 -> 2.9 VALU instructions, but its 114 KB of W per work-group leave one wave per SIMD:
     // 10.06 -> 10.49 ms.)
-    const int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
+    int nt = a.O <= 32 ? 1 : (a.O <= 64 ? 2 : 4);
     if (a.O % (32 * nt)) return 1;
     const int nshare = a.groups / a.xmod;
+    // Launches that cannot fill the chip (the small geometries' patch embedding: 2048 rows x 64 columns = 16 work-groups of two column
+    // tiles): a wave's MFMA chain IS the kernel time there, so one column tile per work-group -- twice (four times) the work-groups, half
+    // (a quarter of) the chain each; the basis is re-evaluated per column tile, the k order of every output is unchanged (bitwise equal).
+    if (nt > 1 && ((a.M + BM - 1) / BM) * (long long)a.groups * (a.O / (32 * nt)) < N_CU) nt = 1;
     // q|k|v sharing one basis evaluation (NSH = 3) triples the MFMA chain of every wave; when the launch has fewer
     // work-groups than CUs (the small geometries: 50 row tiles x 2 heads) the chain length IS the kernel time, so each
     // projection gets its own work-groups there and re-evaluates the basis
