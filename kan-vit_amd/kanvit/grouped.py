@@ -36,8 +36,29 @@ class _StackParams(torch.autograd.Function):
         return grad.contiguous().unbind(0)
 
 
-def stack_params(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+class _StackPermuted(torch.autograd.Function):
+    """torch.stack over per-head parameters WITH a layout permutation, one kernel each way: forward stacks permuted VIEWS (torch.cat's
+    strided-input path writes the packed layout directly -- stack followed by permute + reshape was a cat launch and a copy launch per
+    block), backward makes the incoming gradient contiguous in the parameters' own layout once and hands out its unbound slices."""
+
+    @staticmethod
+    def forward(ctx, perm, *tensors):
+        ctx.inv = tuple(sorted(range(len(perm)), key=lambda a: perm[a]))
+        return torch.stack([t.permute(*perm) for t in tensors])
+
+    @staticmethod
+    def backward(ctx, grad):
+        inv = (0,) + tuple(1 + a for a in ctx.inv)
+        return (None,) + grad.permute(*inv).contiguous().unbind(0)
+
+
+def stack_params(tensors: Sequence[torch.Tensor], perm: Sequence[int] = None) -> torch.Tensor:
+    """torch.stack(tensors) -- of tensors.permute(perm) when perm is given -- whose backward costs one kernel (see above)."""
     tensors = list(tensors)
+    if perm is not None:
+        if any(t.requires_grad for t in tensors) and torch.is_grad_enabled():
+            return _StackPermuted.apply(tuple(perm), *tensors)
+        return torch.stack([t.permute(*perm) for t in tensors])
     if any(t.requires_grad for t in tensors) and torch.is_grad_enabled():
         return _StackParams.apply(*tensors)
     return torch.stack(tensors)
@@ -87,7 +108,7 @@ def run_qkv(q_layers: Sequence, k_layers: Sequence, v_layers: Sequence, x2d: tor
     # Pack ALL 3*H layers with one stack + one layout transform (a handful of launches) instead of a
     # permute-copy per head (3*H launches forward and again backward: 880 tiny kernels per ViT-B step).
     if isinstance(layers[0], torch.nn.Linear):
-        w = stack_params([m.weight for m in layers]).permute(0, 2, 1)
+        w = stack_params([m.weight for m in layers], perm=(1, 0))      # [g, I, O]: nn.Linear keeps [O, I]
         bp = None
         bias = None if layers[0].bias is None else stack_params([m.bias for m in layers])
     else:

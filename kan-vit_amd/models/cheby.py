@@ -35,9 +35,9 @@ class ChebyKANLayer(nn.Module):
 
     @staticmethod
     def kan_pack_grouped(layers):
-        c = grouped.stack_params([m.cheby_coeffs for m in layers])                    # [g, I, O, D+1]
-        g, i, o, d1 = c.shape
-        return c.permute(0, 1, 3, 2).reshape(g, i * d1, o), None, None
+        c = grouped.stack_params([m.cheby_coeffs for m in layers], perm=(0, 2, 1))    # [g, I, D+1, O], written in the packed layout
+        g, i, d1, o = c.shape
+        return c.view(g, i * d1, o), None, None
 
     def forward(self, x):
         return grouped.run_single(self, x.reshape(-1, self.inputdim))
