@@ -60,7 +60,7 @@ class TransformerBlock(nn.Module):
 class _ClsToken(torch.autograd.Function):
     """out[:, 0] + pending[:, 0] (model.py:166-169 reads only the class token; the last block's feed-forward output is still
     pending, TransformerBlock.run).  The two inputs receive the SAME gradient -- g in row 0, zeros elsewhere -- so backward builds
-    it once (one fill + one copy instead of two of each; the small geometries count launches)."""
+    it once, as ONE padding launch (the small geometries count launches)."""
 
     @staticmethod
     def forward(ctx, out, pending):
@@ -70,8 +70,7 @@ class _ClsToken(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        full = g.new_zeros(ctx.shape)
-        full[:, 0] = g
+        full = torch.nn.functional.pad(g.unsqueeze(1), (0, 0, 0, ctx.shape[1] - 1))      # [B, N, d]: g in row 0, zeros below
         return full, (full if ctx.pdtype == full.dtype else full.to(ctx.pdtype))      # a bf16 feed-forward output under autocast
 
 
