@@ -182,12 +182,14 @@ int kanvit_layer_bwd_weight(const kanvit_layer_desc* d, const float* x, const fl
  *     dw[i*GP + j][o] = sum_{b,p} phi_j(patch(b, p)[i]) * dy[b, prepend_rows + p, o]
  * x rows come from the NCHW images, dY rows from the token-sequence gradient [B][P + prepend_rows][ldy] as the first block's
  * backward leaves it (class-token rows are stepped over): no transient [B*P, I] patch matrix, no copy of dY.  d as above
- * (M = B*P, `ldy` = row stride of dy); KANVIT_FLAG_BF16_MFMA and KANVIT_FLAG_SINE_DFREQ as for kanvit_layer_bwd_weight.
+ * (M = B*P, `ldy` = row stride of dy); KANVIT_FLAG_SINE_DFREQ as for kanvit_layer_bwd_weight.  Exact fp32: with
+ * KANVIT_FLAG_BF16_MFMA (whose short MFMA phases cannot hide the row walker: measured slower than the copy it saves)
+ * kanvit_patch_embed_bwd_weight_ok() answers 0.
  * kanvit_patch_embed_bwd_weight_ok() (pure host function) says whether the gathering kernels cover the layer: the patch
  * embeddings VisionTransformer builds (model.py:67-80) with ChebyKAN degree 4, SineKAN and FourierKAN at grid 28 (I, O
  * multiples of 32, M >= 256, 32-bit element offsets); otherwise (efficient-KAN: its weight-gradient kernels have no register
- * left for the row walker and measured slower with it) the call returns KANVIT_EINVAL and the caller uses patchify +
- * kanvit_layer_bwd_weight. */
+ * left for the row walker and measured slower with it; bf16 mode) the call returns KANVIT_EINVAL and the caller uses
+ * patchify + kanvit_layer_bwd_weight. */
 typedef struct kanvit_patch_desc {
     int32_t C, H, W;         /* image batch is [B][C][H][W], contiguous                                  */
     int32_t n_patches;       /* patches per side: patch = (H / n_patches) x (W / n_patches) pixels       */

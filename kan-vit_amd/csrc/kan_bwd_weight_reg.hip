@@ -526,10 +526,9 @@ int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t
     if (bf && !HAS_BF) return kv_fail(KANVIT_EINVAL, "internal: this register weight-gradient instantiation has no bf16 form");
     if (a.pg && !HAS_PG) return kv_fail(KANVIT_EINVAL, "internal: this register weight-gradient instantiation has no patch-gather form");
     if constexpr (HAS_PG) {
-        if (a.pg) {
-            if constexpr (HAS_BF) {
-                if (bf) return launch_bwd_weight_reg_one<FAM, GP, NOT, true, JC, true>(a, p, st);
-            }
+        if (a.pg) {      // exact fp32 only: on the bf16 matrix cores the MFMA phases are too short to hide the scalar row walker (SineKAN G = 28:
+                         // 2.76 -> 3.15 ms per pass, ChebyKAN 0.37 -> 0.50 ms -- more than the patch-matrix copies cost), kv_bwd_weight_reg_pg_ok
+            if (bf) return kv_fail(KANVIT_EINVAL, "internal: the patch-gather weight gradient is an exact-fp32 form");
             return launch_bwd_weight_reg_one<FAM, GP, NOT, false, JC, true>(a, p, st);
         }
     }
@@ -704,7 +703,7 @@ int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hip
 // the plans whose kernels exist in the patch-gather form (dispatch_bwd_weight_reg's HAS_PG instantiations): the patch-embedding
 // layers VisionTransformer builds (model.py:67-80: ChebyKAN degree 4, SineKAN / FourierKAN at grid 28)
 bool kv_bwd_weight_reg_pg_ok(const kanvit_layer_desc* d, const BwRegPlan& p) {
-    if (!p.ok || d->groups != 1) return false;
+    if (!p.ok || d->groups != 1 || p.bf) return false;      // (bf16 mode keeps the patch matrix: see launch_bwd_weight_reg)
     // B-splines are NOT among them: their kernels are at the register limit, and the walker's scalar state spilled (19 scalar registers
     // in the 16-row kernel, 16 vector registers in the 32-row one): 2.97 against 2.80 ms for the ViT-B patch embedding, 1.82 against
     // 1.13 ms in bf16 mode -- more than the patch-matrix copy costs.  efficient-KAN's patch embedding keeps the transient patch matrix.

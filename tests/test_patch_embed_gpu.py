@@ -127,8 +127,7 @@ def test_fused_patch_embedding_bf16_mode(t, geom):
             res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
     assert set(res[0][1]) == set(res[1][1])
     assert torch.equal(res[0][0], res[1][0])
-    if t != "efficientkan" and b * npatch * npatch >= 256:
-        assert _gathered_backward(m, chw, npatch, d, b, bf16=True)
+    assert not _gathered_backward(m, chw, npatch, d, b, bf16=True)      # bf16 mode: fused gather forward, patch-matrix weight gradient
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
     sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in m.state_dict().items()}
@@ -178,7 +177,12 @@ def test_patch_embed_bwd_weight_through_the_c_abi(pre, bf16):
     dy = torch.randn(B, P + pre, O, device=DEV)
     d = ops._desc(cfg, B * P, I, I, O, 0)
     pd = _lib.PatchDesc(Cc, H, W, n, pre, 0)
-    assert L.kanvit_patch_embed_bwd_weight_ok(C.byref(d), C.byref(pd)) == 1
+    assert L.kanvit_patch_embed_bwd_weight_ok(C.byref(d), C.byref(pd)) == (0 if bf16 else 1)
+    if bf16:                             # exact fp32 only (the bf16 kernels' short MFMA phases cannot hide the row walker): refused, loudly
+        dw = torch.empty(1, I * 5, O, device=DEV)
+        rc = L.kanvit_patch_embed_bwd_weight(C.byref(d), C.byref(pd), ops._ptr(images), None, ops._ptr(dy), ops._ptr(dw), None, 0, None)
+        assert rc != 0 and b"not covered" in L.kanvit_last_error()
+        return
     nb = int(L.kanvit_patch_embed_bwd_weight_workspace(C.byref(d), C.byref(pd)))
     ws = torch.empty(max(nb // 4, 1), device=DEV)
     dw = torch.full((1, I * 5, O), float("nan"), device=DEV)
