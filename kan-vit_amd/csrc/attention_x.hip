@@ -7,7 +7,7 @@
 // query i sees keys j <= i - (k_len - q_len)), the first k_len - q_len queries have no visible key and its answer for them depends
 // on the bucket sizes -- refused here (KANVIT_EINVAL) instead of imitated.  The ViT path never uses either (attention.hip's kernels: one length, no
 // mask); these kernels cover the rest of the function's domain with the same tile orientation as attention.hip's first form:
-//   forward       work-group = four 32-query tiles of one (batch, head), one per wave; the keys are swept in LDS chunks of 128 rows
+//   forward       work-group = eight 32-query tiles of one (batch, head), one per wave; the keys are swept in LDS chunks of 128 rows
 //                 (K, V images [128][KS]); S^T = K.Q^T with the key index in the accumulator register index -> softmax over the
 //                 chunk in registers, running (max, sum) across chunks (utils.py:199-221) -> O^T = V^T.P^T from registers
 //   backward      rowsum(dO*O) (attn_x_delta_kernel), then a key-stationary kernel (a wave owns a key tile: dK^T, dV^T in
@@ -22,10 +22,12 @@
 #include "kanvit_common.h"
 
 #include <float.h>
+#include <initializer_list>
 
 namespace {
 
-constexpr int XTHR = 256;
+constexpr int XTHR = 512;        // 8 waves: two per SIMD (one LDS chunk of the swept operand serves eight 32-row tiles)
+constexpr int XW = XTHR / 64;
 constexpr float LOG2E_X = 1.4426950408889634f;
 
 struct AttnXArgs {
@@ -46,6 +48,7 @@ struct AttnXArgs {
     long long msb, msh, msq, msk;
     long long qsb, qsh, qsn, ksb, ksh, ksn, vsb, vsh, vsn, osb, osh, osn;
     int B, H, Nq, Nk, D, causal, nqt, nkt;
+    int vec;          // rows are 16-byte aligned pieces (D % 4 == 0, strides % 4 == 0, aligned bases): tile fills use 16-byte loads
     float scale;
 };
 
@@ -78,8 +81,20 @@ __device__ __forceinline__ unsigned x_dead_bits(const AttnXArgs& a, const unsign
 // dst[rows][KS] <- src rows row0.. (row stride stride_n), zero beyond n_valid rows and D columns
 template <int DT>
 __device__ __forceinline__ void x_load_tile(float* __restrict__ dst, const float* __restrict__ src, long long stride_n, int row0,
-                                            int rows, int n_valid, int D, int tid, int nthr) {
+                                            int rows, int n_valid, int D, int tid, int nthr, bool vec) {
     constexpr int W = 32 * DT, KS = W + 1;
+    if (vec) {
+        constexpr int W4 = W / 4;
+        for (int idx = tid; idx < rows * W4; idx += nthr) {
+            const int r = idx / W4, c = (idx - r * W4) * 4;
+            const int n = row0 + r;
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (n < n_valid && c < D) t = *reinterpret_cast<const f32x4*>(src + (long long)n * stride_n + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[r * KS + c + e] = t[e];
+        }
+        return;
+    }
     for (int idx = tid; idx < rows * W; idx += nthr) {
         const int r = idx / W, c = idx - r * W;
         const int n = row0 + r;
@@ -100,7 +115,7 @@ __device__ __forceinline__ void x_store_tile(float* __restrict__ dstg, long long
 
 constexpr int XCH = 4;            // tiles of 32 rows per LDS chunk of the swept operand (128 rows)
 
-// forward: grid (B*H, ceil(q tiles / 4)); a wave owns a 32-query tile and sweeps the keys in chunks of XCH tiles with the running
+// forward: grid (B*H, ceil(q tiles / 8)); a wave owns a 32-query tile and sweeps the keys in chunks of XCH tiles with the running
 // (max, sum) rescale of utils.py:199-221 -- in this orientation (O^T[d][query]: the query is the lane) the rescale of the partial
 // output is one multiplication of the lane's accumulators by a lane-private factor
 template <int DT>
@@ -121,9 +136,9 @@ __global__ __launch_bounds__(XTHR) void attn_x_fwd_kernel(const AttnXArgs a) {
     const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
 
     const float sc2 = a.scale * LOG2E_X;
-    const int qt = blockIdx.y * 4 + wave;        // tiles past nqt run on zero rows and store nothing
+    const int qt = blockIdx.y * XW + wave;       // tiles past nqt run on zero rows and store nothing
     const int qrow = qt * 32 + l31;
-    x_load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+    x_load_tile<DT>(Q_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64, a.vec);
     __syncthreads();
     float qf[16 * DT];
 #pragma unroll
@@ -138,8 +153,8 @@ __global__ __launch_bounds__(XTHR) void attn_x_fwd_kernel(const AttnXArgs a) {
 
     for (int kc = 0; kc < nkt; kc += XCH) {
         __syncthreads();                         // every wave is done with the previous chunk
-        x_load_tile<DT>(K_s, kb, a.ksn, kc * 32, CH, a.Nk, D, tid, XTHR);
-        x_load_tile<DT>(V_s, vb, a.vsn, kc * 32, CH, a.Nk, D, tid, XTHR);
+        x_load_tile<DT>(K_s, kb, a.ksn, kc * 32, CH, a.Nk, D, tid, XTHR, a.vec);
+        x_load_tile<DT>(V_s, vb, a.vsn, kc * 32, CH, a.Nk, D, tid, XTHR, a.vec);
         __syncthreads();
         f32x16 sacc[XCH];
         unsigned dbits[XCH];
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_x_delta_kernel(const AttnXArgs a) {
     if (row < rows && sub == 0) a.delta[row] = s;
 }
 
-// dK, dV: key-stationary (utils.py:262-291).  grid (B*H, ceil(key tiles / 4)); a wave owns a 32-key tile (K, V fragments in registers,
+// dK, dV: key-stationary (utils.py:262-291).  grid (B*H, ceil(key tiles / 8)); a wave owns a 32-key tile (K, V fragments in registers,
 // dK^T / dV^T in accumulators) and sweeps the queries in LDS chunks of XCH tiles.
 template <int DT>
 __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) {
@@ -252,15 +267,15 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) 
     const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
     const float sc2 = a.scale * LOG2E_X;
 
-    const int jt = blockIdx.y * 4 + wave;
+    const int jt = blockIdx.y * XW + wave;
     const int key = jt * 32 + l31;
     float kf[16 * DT], vf[16 * DT];
-    x_load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
+    x_load_tile<DT>(T_w, kb, a.ksn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64, a.vec);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 16 * DT; ++s) kf[s] = T_w[l31 * KS + 2 * s + hf];
     __syncthreads();
-    x_load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64);
+    x_load_tile<DT>(T_w, vb, a.vsn, jt * 32, 32, (jt < a.nkt) ? a.Nk : 0, D, lane, 64, a.vec);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 16 * DT; ++s) vf[s] = T_w[l31 * KS + 2 * s + hf];
@@ -275,8 +290,8 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) 
         }
     for (int qc = 0; qc < a.nqt; qc += XCH) {
         __syncthreads();
-        x_load_tile<DT>(Q_s, qb, a.qsn, qc * 32, CH, a.Nq, D, tid, XTHR);
-        x_load_tile<DT>(dO_s, dob, a.osn, qc * 32, CH, a.Nq, D, tid, XTHR);
+        x_load_tile<DT>(Q_s, qb, a.qsn, qc * 32, CH, a.Nq, D, tid, XTHR, a.vec);
+        x_load_tile<DT>(dO_s, dob, a.osn, qc * 32, CH, a.Nq, D, tid, XTHR, a.vec);
         for (int n = tid; n < CH; n += XTHR) {
             const int qn = qc * 32 + n;
             lse_s[n] = (qn < a.Nq) ? a.lse_in[(long long)bh * a.Nq + qn] * LOG2E_X : INFINITY;      // exp2(-inf) = 0 on pad rows
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_kv_kernel(const AttnXArgs a) 
     if (jt < a.nkt) x_store_tile<DT>(dvb, a.vsn, jt * 32, a.Nk, D, T_w, lane);
 }
 
-// dQ: query-stationary mirror of the forward kernel (grid (B*H, ceil(q tiles / 4)); keys swept in LDS chunks of XCH tiles)
+// dQ: query-stationary mirror of the forward kernel (grid (B*H, ceil(q tiles / 8)); keys swept in LDS chunks of XCH tiles)
 template <int DT>
 __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -353,16 +368,16 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
     const unsigned char* mb = a.mask ? a.mask + bi * a.msb + hi * a.msh : nullptr;
     const float sc2 = a.scale * LOG2E_X;
 
-    const int qt = blockIdx.y * 4 + wave;
+    const int qt = blockIdx.y * XW + wave;
     const int qrow = qt * 32 + l31;
     const bool q_ok = (qt < a.nqt) && (qrow < a.Nq);
     float qf[16 * DT], dof[16 * DT];
-    x_load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+    x_load_tile<DT>(T_w, qb, a.qsn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64, a.vec);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 16 * DT; ++s) qf[s] = T_w[l31 * KS + 2 * s + hf];
     __syncthreads();
-    x_load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64);
+    x_load_tile<DT>(T_w, dob, a.osn, qt * 32, 32, (qt < a.nqt) ? a.Nq : 0, D, lane, 64, a.vec);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 16 * DT; ++s) dof[s] = T_w[l31 * KS + 2 * s + hf];
@@ -376,8 +391,8 @@ __global__ __launch_bounds__(XTHR) void attn_x_bwd_q_kernel(const AttnXArgs a) {
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.0f;
     for (int kc = 0; kc < nkt; kc += XCH) {
         __syncthreads();
-        x_load_tile<DT>(K_s, kb, a.ksn, kc * 32, CH, a.Nk, D, tid, XTHR);
-        x_load_tile<DT>(V_s, vb, a.vsn, kc * 32, CH, a.Nk, D, tid, XTHR);
+        x_load_tile<DT>(K_s, kb, a.ksn, kc * 32, CH, a.Nk, D, tid, XTHR, a.vec);
+        x_load_tile<DT>(V_s, vb, a.vsn, kc * 32, CH, a.Nk, D, tid, XTHR, a.vec);
         __syncthreads();
         for (int j = 0; j < XCH && kc + j < nkt; ++j) {
             f32x16 sacc, pacc;
@@ -438,6 +453,8 @@ AttnXArgs x_args(const kanvit_attn_desc* d, const kanvit_attn_ext* e) {
     a.ksb = d->k_stride_b; a.ksh = d->k_stride_h; a.ksn = d->k_stride_n;
     a.vsb = d->v_stride_b; a.vsh = d->v_stride_h; a.vsn = d->v_stride_n;
     a.osb = d->o_stride_b; a.osh = d->o_stride_h; a.osn = d->o_stride_n;
+    a.vec = (d->D % 4 == 0);
+    for (long long sd : {a.qsb, a.qsh, a.qsn, a.ksb, a.ksh, a.ksn, a.vsb, a.vsh, a.vsn, a.osb, a.osh, a.osn}) a.vec = a.vec && (sd % 4 == 0);
     a.mask = (const unsigned char*)e->mask;
     a.msb = e->mask_stride_b; a.msh = e->mask_stride_h; a.msq = e->mask_stride_q; a.msk = e->mask_stride_k;
     return a;
@@ -446,9 +463,9 @@ AttnXArgs x_args(const kanvit_attn_desc* d, const kanvit_attn_ext* e) {
 template <int DT>
 int x_launch_fwd(const AttnXArgs& a, hipStream_t st) {
     constexpr int KS = 32 * DT + 1, CH = XCH * 32;
-    const size_t lds = sizeof(float) * ((size_t)2 * CH * KS + (size_t)4 * 32 * KS);
+    const size_t lds = sizeof(float) * ((size_t)2 * CH * KS + (size_t)XW * 32 * KS);
     KV_ALLOW_LDS(160 * 1024, (attn_x_fwd_kernel<DT>));
-    hipLaunchKernelGGL((attn_x_fwd_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nqt + 3) / 4)), dim3(XTHR), lds, st, a);
+    hipLaunchKernelGGL((attn_x_fwd_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nqt + XW - 1) / XW)), dim3(XTHR), lds, st, a);
     KV_LAUNCH_CHECK("attn_x_fwd_kernel");
     return 0;
 }
@@ -456,13 +473,13 @@ int x_launch_fwd(const AttnXArgs& a, hipStream_t st) {
 template <int DT>
 int x_launch_bwd(const AttnXArgs& a, hipStream_t st) {
     constexpr int KS = 32 * DT + 1, CH = XCH * 32;
-    const size_t lds_kv = sizeof(float) * ((size_t)2 * CH * KS + 2 * (size_t)CH + (size_t)4 * 32 * KS);
-    const size_t lds_q = sizeof(float) * ((size_t)2 * CH * KS + (size_t)4 * 32 * KS);
+    const size_t lds_kv = sizeof(float) * ((size_t)2 * CH * KS + 2 * (size_t)CH + (size_t)XW * 32 * KS);
+    const size_t lds_q = sizeof(float) * ((size_t)2 * CH * KS + (size_t)XW * 32 * KS);
     KV_ALLOW_LDS(160 * 1024, (attn_x_bwd_kv_kernel<DT>));
     KV_ALLOW_LDS(160 * 1024, (attn_x_bwd_q_kernel<DT>));
-    hipLaunchKernelGGL((attn_x_bwd_kv_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nkt + 3) / 4)), dim3(XTHR), lds_kv, st, a);
+    hipLaunchKernelGGL((attn_x_bwd_kv_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nkt + XW - 1) / XW)), dim3(XTHR), lds_kv, st, a);
     KV_LAUNCH_CHECK("attn_x_bwd_kv_kernel");
-    hipLaunchKernelGGL((attn_x_bwd_q_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nqt + 3) / 4)), dim3(XTHR), lds_q, st, a);
+    hipLaunchKernelGGL((attn_x_bwd_q_kernel<DT>), dim3((unsigned)(a.B * a.H), (unsigned)((a.nqt + XW - 1) / XW)), dim3(XTHR), lds_q, st, a);
     KV_LAUNCH_CHECK("attn_x_bwd_q_kernel");
     return 0;
 }
@@ -478,6 +495,7 @@ int kanvit_attn_x_fwd(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const
     if (d->B == 0) return 0;
     AttnXArgs a = x_args(d, e);
     a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
+    a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     return d->D <= 32 ? x_launch_fwd<1>(a, st) : x_launch_fwd<2>(a, st);
 }
@@ -498,6 +516,7 @@ int kanvit_attn_x_bwd(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const
     AttnXArgs a = x_args(d, e);
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse_in = lse; a.d_o = d_o;
     a.dq = dq; a.dk = dk; a.dv = dv; a.delta = (float*)workspace; a.delta_in = (const float*)workspace;
+    a.vec = a.vec && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)d->B * d->H * d->N;
     hipLaunchKernelGGL(attn_x_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
