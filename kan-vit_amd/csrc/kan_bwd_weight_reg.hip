@@ -24,6 +24,7 @@ template <int FAM, int GP, int NOT, bool BF, int JC = GP, bool PG = false>
 __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg,
                                                                  int shared, int nbg) {
     static_assert(!(PG && FAM == KV_RBF), "FastKAN's patch embedding reads u = LayerNorm(x): no gather form");
+    static_assert(!(PG && BF), "the gather form is exact fp32 (bf16 MFMA phases are too short to hide the row walker: launch_bwd_weight_reg)");
     constexpr int NJC = (GP + JC - 1) / JC;       // wide bases (G = 28) are contracted in NJC windows of JC basis functions,
                                                   // each its own wave unit (every window regenerates only its own values)
     constexpr bool RBF = (FAM == KV_RBF);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     // stepped row by row BETWEEN the MFMA groups of the block being contracted (walk_fill below): run as one cluster in front of the
     // loads, its ~200 dependent scalar instructions per block sat in front of an idle matrix pipe (one wave per SIMD: +17 % on the
     // ChebyKAN launch).
-    constexpr int TPB = BF ? 16 : 2 * UB;      // rows of a block: lane half hf takes rows 8hf + t (bf16) / 2t + hf (fp32)
+    constexpr int TPB = 2 * UB;                // rows of a block (gather form, fp32): lane half hf takes row 2t + hf
     PatchWalk walk;
     int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0, pg_wtok = 0;
     int psx[PG ? TPB : 1], psdy[PG ? TPB : 1];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
             for (int t = 0; t < NTOK; ++t) {
                 // this lane's row is k0 (lower lane half) or k1 (upper): base + (difference & lane mask) -- written as a select, the
                 // pair becomes a dynamically indexed read of psx[] and a chain of seven v_cndmask per value
-                const int k0 = BF ? t : 2 * t, k1 = BF ? 8 + t : 2 * t + 1;
+                const int k0 = 2 * t, k1 = 2 * t + 1;
                 const int xo = psx[k0] + ((psx[k1] - psx[k0]) & pg_hm), dyr = psdy[k0] + ((psdy[k1] - psdy[k0]) & pg_hm);
                 rx[q][t] = a.x[xo + pg_f];
 #pragma unroll
@@ -234,8 +235,6 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
                     unsigned af[JC][4];
 #pragma unroll
                     for (int ep = 0; ep < 4; ++ep) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) walk_fill(4 * ep + k);      // (patch gather) the next block's rows, spread over the basis evaluations
                         BasisGenP<FAM, JC, J0C> g0_ = proto, g1_ = proto;
                         g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
                         g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
@@ -307,9 +306,10 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
 // Everything else as above: wave units (basis group, column-tile set, window, feature block) flattened over the grid,
 // compile-time window start, scalar wave index, operands prefetched PD blocks ahead, slabs + ordered reduce.
 // =============================================================================================
-template <int FAM, int GP, int JC, int NC, bool PG = false>
+// (No patch-gather form: with the row walker of kan_bwd_weight_reg_kernel this kernel spilled 19 scalar registers into vector lanes and ran
+// the ViT-B efficient-KAN patch embedding in 2.98 instead of 2.72-2.80 ms -- more than the two copies the gather removes; measured twice, removed.)
+template <int FAM, int GP, int JC, int NC>
 __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg, int shared, int nbg) {
-    static_assert(!(PG && FAM == KV_RBF), "FastKAN's patch embedding reads u = LayerNorm(x): no gather form");
     constexpr int NJC = (GP + JC - 1) / JC;
     static_assert(GP % JC == 0 && (NJC == 3 || NJC == 1), "whole windows: three of three values (B-spline) or all nine (FastKAN)");
     constexpr bool RBF = (FAM == KV_RBF);
@@ -373,38 +373,7 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
         float rx[PD][UB], rdy[PD][UB][NC];
         float2 ru[RBF ? PD : 1][RBF ? UB : 1];      // FastKAN: u (in .x), or the token's (mean, rstd)
         auto tok_of = [&](int blk, int t) -> int { return 4 * (blk * UB + t) + tq; };
-        PatchWalk walk;                       // patch gather: see kan_bwd_weight_reg_kernel
-        int pg_f = 0, pg_x0 = 0, pg_dy0 = 0, pg_len = 0, pg_wtok = 0;
-        int psx[4], psdy[4];                  // offsets of the four rows of the next block to be requested
-        const int pg_m1 = -(int)(tq == 1), pg_m2 = -(int)(tq == 2), pg_m3 = -(int)(tq == 3);
-        if constexpr (PG) {
-            static_assert(!PG || UB == 1, "one step of four rows per block");
-            walk.init(a, __builtin_amdgcn_readfirstlane((int)ms));
-            pg_x0 = walk.xoff;
-            pg_dy0 = walk.dyoff;
-            pg_len = __builtin_amdgcn_readfirstlane(len);
-            pg_f = kv_patch_feature_offset(a, f);
-        }
-        auto walk_fill = [&](int k) {
-            if constexpr (PG) {
-                const bool in = pg_wtok < pg_len;
-                psx[k] = in ? walk.xoff : pg_x0;
-                psdy[k] = in ? walk.dyoff : pg_dy0;
-                walk.step();
-                ++pg_wtok;
-            }
-        };
         auto load_block = [&](int q, int blk) {
-            if constexpr (PG) {
-                // lane group tq takes row tq of the block: base + the masked differences (a select tree becomes a dynamically
-                // indexed read of psx[]: a v_cndmask chain per value)
-                const int xo = psx[0] + (((psx[1] - psx[0]) & pg_m1) | ((psx[2] - psx[0]) & pg_m2) | ((psx[3] - psx[0]) & pg_m3));
-                const int dyr = psdy[0] + (((psdy[1] - psdy[0]) & pg_m1) | ((psdy[2] - psdy[0]) & pg_m2) | ((psdy[3] - psdy[0]) & pg_m3));
-                rx[q][0] = a.x[xo + pg_f];
-#pragma unroll
-                for (int i = 0; i < NC; ++i) rdy[q][0][i] = a.dy[dyr + dyo[i]];
-                return;
-            }
 #pragma unroll
             for (int t = 0; t < UB; ++t) {
                 int tk = tok_of(blk, t);
@@ -420,19 +389,9 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
             }
         };
         const int nblk = (len + 4 * UB - 1) / (4 * UB);
-        if constexpr (PG) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) walk_fill(k);
-        }
 #pragma unroll
         for (int q = 0; q < PD; ++q)
-            if (q < nblk) {
-                load_block(q, q);
-                if constexpr (PG) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) walk_fill(k);
-                }
-            }
+            if (q < nblk) load_block(q, q);
         // A block is copied out of the ring and its slot refilled BEFORE its MFMAs (prefetch distance PD blocks).  Reading the ring
         // registers directly and refilling after the MFMAs saves NC + 1 moves per step but shortens the distance to PD - 1 blocks:
         // measured slower (767 -> 812 us on the ViT-B q|k|v launch) -- at two waves per SIMD this kernel lives on its prefetch depth.
@@ -459,10 +418,6 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
                         gen.init(cx[t], cu[t]);
 #pragma unroll
                         for (int j = 0; j < JC; ++j) {
-                            if constexpr (PG) {                                   // the next block's four rows, spread over the JC MFMA groups
-                                if (JC >= 4) { if (j < 4) walk_fill(j); }
-                                else { walk_fill(j); if (j == JC - 1) for (int k = JC; k < 4; ++k) walk_fill(k); }
-                            }
                             const float av = ok[t] ? gen.next(j) : 0.0f;          // rows past the slab contribute nothing (JC selects, not NC)
 #pragma unroll
                             for (int i = 0; i < NC; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
@@ -538,19 +493,12 @@ int launch_bwd_weight_reg(LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t
     return launch_bwd_weight_reg_one<FAM, GP, NOT, false, JC, false>(a, p, st);
 }
 
-template <int FAM, int GP, int JC, int NC, bool HAS_PG = false>
+template <int FAM, int GP, int JC, int NC>
 int launch_bwd_weight_reg16(LayerArgs& a, const BwRegPlan& p, hipStream_t st) {
     const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
     dim3 grid((unsigned)((units * p.slabs + 3) / 4), 1, 1);
-    if (a.pg && !HAS_PG) return kv_fail(KANVIT_EINVAL, "internal: this 16-row weight-gradient instantiation has no patch-gather form");
-    if constexpr (HAS_PG) {
-        if (a.pg) {
-            hipLaunchKernelGGL((kan_bwd_weight_reg16_kernel<FAM, GP, JC, NC, true>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
-            KV_LAUNCH_CHECK("kan_bwd_weight_reg16_kernel");
-            return 0;
-        }
-    }
-    hipLaunchKernelGGL((kan_bwd_weight_reg16_kernel<FAM, GP, JC, NC, false>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
+    if (a.pg) return kv_fail(KANVIT_EINVAL, "internal: the 16-row weight-gradient kernel has no patch-gather form");
+    hipLaunchKernelGGL((kan_bwd_weight_reg16_kernel<FAM, GP, JC, NC>), grid, dim3(256), 0, st, a, p.nfb, p.nos, p.tiles_per_bg, p.shared, p.nbg);
     KV_LAUNCH_CHECK("kan_bwd_weight_reg16_kernel");
     return 0;
 }
