@@ -70,15 +70,13 @@ def self_launch(n: int) -> int:
     per GPU under torch.distributed.run, exactly the command line the docstring gives -- BEFORE this process has made any GPU
     call (it never does: it only relays), pass rank 0's single JSON line through to stdout and return the launcher's exit
     code.  No exec: a process that may have touched the GPU must not be replaced on this pool."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this host driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous on a port IT binds (endpoint port 0) -- nothing is probed and released
+    # here for another process to take in between; --local-addr keeps every address on 127.0.0.1 (the hostname may not resolve)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     line = None
@@ -271,7 +269,8 @@ def main():
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and not force_dp and wl["d"] <= 128)
     # fused=True: the same Adam update (train.py:33 uses optim.Adam) as one multi-tensor kernel per chunk instead of ~8
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=use_graph, fused=True)
-    reducer = kdp.GradReducer(model.parameters(), bucket_mib=args.bucket_mib, always_reduce=force_dp) if (world > 1 or force_dp) else None
+    reducer = kdp.GradReducer(model.parameters(), bucket_mib=args.bucket_mib, always_reduce=force_dp,
+                              timing=True) if (world > 1 or force_dp) else None
     crit = torch.nn.CrossEntropyLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(wl["batch"], *wl["chw"], device=dev, generator=g)
@@ -284,11 +283,11 @@ def main():
             loss = crit(model(x), y)
         if reducer is not None:
             reducer.zero_grad()
+            reducer.scale_loss(loss).backward()        # sums over ranks become means inside the collective / the loss: no pass over the buckets
+            reducer.finish()
         else:
             opt.zero_grad()
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
+            loss.backward()
         opt.step()
         return loss
 
@@ -333,6 +332,8 @@ def main():
     else:
         if not args.no_kernel_timer:
             ops.timer = ops.KernelTimer()
+        if reducer is not None:
+            reducer.reset_timing()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -365,6 +366,10 @@ def main():
                        "kanvit_switches": klib.active_config(), "loss_after": round(final_loss, 4)},
         }
         out.update(roofline_report(kern, args.steps, args.workload, wl["batch"]))
+        if reducer is not None:
+            # gradient exchange of rank 0 over the timed steps: all-reduce time on the stream the collectives are issued from,
+            # the part of it backward did not hide (what the compute stream waited in finish()), bucket count and bytes
+            out["comm"] = reducer.comm_summary()
         if world == 1 and args.amp == "off" and not use_graph and not force_dp and not args.no_amp_leg:
             # Secondary measurement, same run: the same step with the stock GEMMs under bf16 autocast and the kanvit kernels on
             # the bf16 matrix cores (BASELINE configs[2]/[4] name bf16 for the 224x224 streams).  `value` above is the fp32 path.

@@ -437,6 +437,7 @@ int x_check(const kanvit_attn_desc* d, const kanvit_attn_ext* e, const char* who
     if (d->B < 0 || d->H < 1 || d->N < 1 || e->Nk < 1 || d->D < 1) return kv_fail(KANVIT_EINVAL, "%s: bad sizes", who);
     if (d->D > KANVIT_ATTN_MAX_D || (d->D & 1)) return kv_fail(KANVIT_EINVAL, "%s: D=%d must be even and <= %d", who, d->D, KANVIT_ATTN_MAX_D);
     if ((long long)d->B * d->H > 0x7fffffffLL) return kv_fail(KANVIT_EINVAL, "%s: B*H too large", who);
+    if (!(d->scale > 0.0f)) return kv_fail(KANVIT_EINVAL, "%s: scale=%g must be positive (the running maximum is taken over the raw scores)", who, (double)d->scale);
     if (d->causal && e->Nk > d->N)
         return kv_fail(KANVIT_EINVAL, "%s: causal with k_len=%d > q_len=%d is ill-defined in the reference (utils.py:169,183: the first k_len - q_len queries see no key)", who, e->Nk, d->N);
     if (d->flags & KANVIT_FLAG_BF16_MFMA) return kv_fail(KANVIT_EINVAL, "%s: the general attention kernels are exact fp32 (no KANVIT_FLAG_BF16_MFMA)", who);

@@ -344,6 +344,8 @@ int kanvit_patch_embed_bwd_weight(const kanvit_layer_desc* d, const kanvit_patch
     }
     if (!images || !dy) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: null images/dy");
     if (needs_bparams(d->family) && !bparams) return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: family %d needs bparams", d->family);
+    if ((d->flags & KANVIT_FLAG_SINE_DFREQ) && !kanvit_layer_sine_dfreq_ok(d))     // as kanvit_layer_bwd_weight: never hand plain dW back as Q
+        return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: KANVIT_FLAG_SINE_DFREQ is not available for this layer (kanvit_layer_sine_dfreq_ok)");
     if (!kanvit_patch_embed_bwd_weight_ok(d, p))
         return kv_fail(KANVIT_EINVAL, "kanvit_patch_embed_bwd_weight: layer / geometry not covered by the gathering weight-gradient kernels "
                                       "(kanvit_patch_embed_bwd_weight_ok); use patchify + kanvit_layer_bwd_weight");

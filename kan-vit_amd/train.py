@@ -143,11 +143,11 @@ def main(args, batches=None, init_state=None):
             loss = criterion(y_hat.float(), y)
         if reducer is not None:
             reducer.zero_grad()
+            reducer.scale_loss(loss).backward()     # mean over ranks inside the collective (RCCL AVG) or the loss: kanvit/dp.py
+            reducer.finish()
         else:
             optimizer.zero_grad()
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
+            loss.backward()
         optimizer.step()
         return loss.detach(), y_hat.detach()
 

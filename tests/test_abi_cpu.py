@@ -230,3 +230,35 @@ def test_assembly_helpers_validate_arguments_without_a_gpu(lib):
     assert b"kanvit_relu_bwd_bias" in lib.kanvit_last_error()
     assert lib.kanvit_relu_bwd_bias(4, 8, p, p, p, p, None, 0, None) != 0             # workspace missing
     assert lib.kanvit_relu_bwd_bias_workspace(25216, 3072) % 16 == 0 and lib.kanvit_relu_bwd_bias_workspace(0, 8) == 0
+
+
+def test_patch_embed_weight_gradient_refuses_the_frequency_flag_on_other_families(lib):
+    """KANVIT_FLAG_SINE_DFREQ asks for Q = sum_m dY x cos(.) instead of dW; a family that has no such operand must be refused, as
+    kanvit_layer_bwd_weight does -- never handed plain dW back as if it were Q.  Host-side refusal: no GPU needed."""
+    from kanvit import _lib, ops
+    pd = _lib.PatchDesc(3, 224, 224, 14, 1, 0)
+    d = ops._desc(ops.LayerCfg(_lib.CHEBY, 768, 768, 5, flags=_lib.FLAG_SINE_DFREQ), 2 * 196, 768, 768, 768, 0)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.kanvit_patch_embed_bwd_weight(ctypes.byref(d), ctypes.byref(pd), p, None, p, p, None, 0, None)
+    assert rc == -22 and b"SINE_DFREQ" in lib.kanvit_last_error()
+    assert lib.kanvit_layer_bwd_weight(ctypes.byref(d), p, None, None, p, p, None, 0, None) == -22
+
+
+def test_general_attention_refuses_a_non_positive_scale(lib):
+    from kanvit import _lib
+    a = _lib.AttnDesc(B=1, H=1, N=40, D=32, scale=-0.5)
+    e = _lib.AttnExt(Nk=50)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.kanvit_attn_x_fwd(ctypes.byref(a), ctypes.byref(e), p, p, p, p, p, None) == -22
+    assert b"scale" in lib.kanvit_last_error()
+
+
+def test_variant_build_script_has_no_source_list_of_its_own():
+    """tools/build_variant.sh (A/B builds loaded through KANVIT_LIB) must compile exactly kanvit/build.py's SOURCES with its FLAGS:
+    round 3's copy of the list had lost attention_x.hip and its library failed to load."""
+    from kanvit import build
+    sh = open(os.path.join(ROOT, "tools", "build_variant.sh")).read()
+    assert "build.SOURCES" in sh and "build.FLAGS" in sh
+    assert not any(s[:-4] + " " in sh for s in build.SOURCES)          # no hard-coded names left

@@ -84,11 +84,10 @@ def test_qkv_bf16_against_rounded_and_exact_oracle(fam, geom):
     # flag (include/kanvit.h: the flag allows bf16 products, exact ones are always valid; the bf16 tile kernel is slower there):
     # those two must match one of the two specified arithmetics
     exact_ok = fam == "sine"
-    exact_w_ok = False
     err = min(maxrel(xg.grad, gx_t), maxrel(xg.grad, gx_e)) if exact_ok else maxrel(xg.grad, gx_t)
     assert err < TIGHT, (fam, geom, "dx", err)
     for k, g in gp_t.items():
-        err = min(maxrel(got[k], g), maxrel(got[k], gp_e[k])) if ((exact_ok and k.endswith("freq")) or exact_w_ok) else maxrel(got[k], g)
+        err = min(maxrel(got[k], g), maxrel(got[k], gp_e[k])) if (exact_ok and k.endswith("freq")) else maxrel(got[k], g)
         assert err < TIGHT, (fam, geom, k, err)
     # loose: bf16 noise against the unrounded oracle (d freq is one cancelling sum over all rows, features and outputs: 3x)
     assert 1e-5 < fro(y, y_e) < LOOSE, (fam, geom, fro(y, y_e))

@@ -25,7 +25,7 @@ def _make_model():
                                torch.nn.Linear(32, 5))
 
 
-def _worker(rank, world, port, overlap, bucket_mib, out):
+def _worker(rank, world, port, overlap, bucket_mib, out, scaled=True):
     sys.path.insert(0, os.path.join(ROOT, "kan-vit_amd"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,27 +39,31 @@ def _worker(rank, world, port, overlap, bucket_mib, out):
     g = torch.Generator().manual_seed(42)
     X, Y = torch.randn(16, 12, generator=g), torch.randint(0, 5, (16,), generator=g)
     lo, hi = kdp.shard_batch(16, rank, world)
-    red = kdp.GradReducer(model.parameters(), bucket_mib=bucket_mib, overlap=overlap)
+    red = kdp.GradReducer(model.parameters(), bucket_mib=bucket_mib, overlap=overlap, timing=True)
+    assert red.average == "loss"                     # gloo has no ReduceOp.AVG: the mean comes from the pre-scaled loss
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     grads0 = None
     for it in range(3):
         loss = torch.nn.functional.cross_entropy(model(X[lo:hi]), Y[lo:hi])
         red.zero_grad()
-        loss.backward()
+        # scaled: the documented protocol (no pass over the buckets after the waits); unscaled: a caller that forgot
+        # scale_loss() -- finish() must notice and fall back to its one multi-tensor mul_
+        (red.scale_loss(loss) if scaled else loss).backward()
         red.finish()
         if it == 0:
             grads0 = [p.grad.clone() for p in model.parameters()]
         opt.step()
+    comm = red.comm_summary()
     torch.save({"grads0": grads0, "params": [p.detach().clone() for p in model.parameters()],
-                "nbuckets": len(red.buckets)}, out + f".{rank}")
+                "nbuckets": len(red.buckets), "comm": comm}, out + f".{rank}")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap,scaled", [(True, True), (False, True), (True, False)])
 @pytest.mark.parametrize("bucket_mib", [64.0, 0.001])
-def test_dp2_matches_single_process(tmp_path, overlap, bucket_mib):
+def test_dp2_matches_single_process(tmp_path, overlap, bucket_mib, scaled):
     out = str(tmp_path / "r")
-    mp.spawn(_worker, args=(2, _free_port(), overlap, bucket_mib, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), overlap, bucket_mib, out, scaled), nprocs=2, join=True)
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     # single-process reference: the whole batch of 16
     model = _make_model()
@@ -80,6 +84,10 @@ def test_dp2_matches_single_process(tmp_path, overlap, bucket_mib):
         assert torch.equal(a, b)
         assert torch.allclose(a, c.detach(), rtol=1e-4, atol=1e-6)
     assert r0["nbuckets"] == (1 if bucket_mib > 1 else 4)
+    comm = r0["comm"]                                                 # the record bench.py prints as `comm`
+    assert comm["buckets"] == r0["nbuckets"] and comm["world"] == 2 and comm["steps"] == 3 and comm["backend"] == "gloo"
+    assert comm["bytes_per_step"] == sum(comm["bucket_bytes"]) == 4 * sum(p.numel() for p in model.parameters())
+    assert comm["exposed_ms_per_step"] >= 0.0 and comm["average"] == "loss"
 
 
 def test_shard_batch_covers_everything():
@@ -92,6 +100,27 @@ def test_shard_batch_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _avg_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "kan-vit_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kanvit import dp as kdp
+    try:
+        kdp.GradReducer(_make_model().parameters(), average="avg")
+        res = "accepted"
+    except ValueError as e:
+        res = str(e)
+    open(out + f".{rank}", "w").write(res)
+    dist.destroy_process_group()
+
+
+def test_collective_average_is_refused_where_the_backend_has_none(tmp_path):
+    """ReduceOp.AVG exists on RCCL only; on gloo the reducer must say so at construction instead of failing in a hook."""
+    out = str(tmp_path / "a")
+    mp.spawn(_avg_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert "ReduceOp.AVG" in open(out + ".0").read()
 
 
 def test_reducer_single_process_is_a_noop():

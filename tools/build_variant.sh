@@ -7,8 +7,11 @@ N=$1; shift
 O=$R/kan-vit_amd/kanvit/_ab; mkdir -p $O/obj_$N
 cd $R/kan-vit_amd/csrc
 pids=()
-for f in kan_tile kan_fwd_reg kan_fwd_reg_bf16 kan_bwd_input_reg kan_bwd_input_reg_bf16 kan_bwd_weight_reg kan_layer attention addln split3 ff_small ff_epilogue kan_tiny; do
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -fno-finite-math-only -fvisibility=hidden -I ../../include "$@" -c $f.hip -o $O/obj_$N/$f.o &
+# sources and flags come from kanvit/build.py: the two builds cannot drift (tests/test_abi_cpu.py checks this file has no list of its own)
+SRCS=$(python3 -c "import sys; sys.path.insert(0, '$R/kan-vit_amd/kanvit'); import build; print(' '.join(s[:-4] for s in build.SOURCES))")
+FLAGS=$(python3 -c "import sys; sys.path.insert(0, '$R/kan-vit_amd/kanvit'); import build; print(' '.join(build.FLAGS))")
+for f in $SRCS; do
+  hipcc $FLAGS -I ../../include "$@" -c $f.hip -o $O/obj_$N/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
