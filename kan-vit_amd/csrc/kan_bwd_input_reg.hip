@@ -32,9 +32,18 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
     constexpr bool RBF = (FAM == KV_RBF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int gx = blockIdx.x;
-    const long long m0 = (long long)blockIdx.y * BM;
     const int nshare = a.groups / a.xmod;
     const int nci = a.I / IC, ncn = a.O / 32;
+    // launch tail (kv_tail_first_tile; never set for SINE, whose d freq partials are per row tile): grid rows >= tail_y0 are row
+    // tile tail_y0 + t / nci restricted to the ONE feature chunk t % nci -- dx columns are independent, so nothing is summed twice
+    int by = (int)blockIdx.y, ci0 = 0, ci1 = nci;
+    if (by >= a.tail_y0) {
+        const int t = by - a.tail_y0, tl = t / nci;
+        ci0 = t - tl * nci;
+        ci1 = ci0 + 1;
+        by = a.tail_y0 + tl;
+    }
+    const long long m0 = (long long)by * BM;
     const int mrem = (m0 + BM <= a.M) ? BM : (int)(a.M - m0);
     const int row = wave * 32 + l31;
     const bool row_ok = row < mrem;
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
     };
 
     const int spc = nshare * ncn;                 // steps per feature chunk
-    const int T = nci * spc;
+    const int T = (ci1 - ci0) * spc;
     f32x16 acc[KT];
     float dxacc[FPH];
     float xv[FPH];
@@ -107,8 +116,8 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
     if constexpr (RBF) {
         if (a.ln) ln_st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
     }
-    int ci = 0, p = 0, cn = 0;
-    load_w(0, gx, 0);
+    int ci = ci0, p = 0, cn = 0;
+    load_w(ci0, gx, 0);
     load_dy(gx, 0);
     store_w(0);
     __syncthreads();
@@ -267,16 +276,17 @@ __global__ __launch_bounds__(256, (FAM == KV_SINE || FAM == KV_FOURIER) ? 1 : 2)
             const int pp = j / GP, gg = j - pp * GP;
             const float* src = dfq_s + (pp * 4) * GP + gg;
             const float v = ((src[0] + src[GP]) + src[2 * GP]) + src[3 * GP];
-            a.dparam[((long long)blockIdx.y * a.groups + (pp * a.xmod + gx)) * a.G + gg] = v;
+            a.dparam[((long long)by * a.groups + (pp * a.xmod + gx)) * a.G + gg] = v;
         }
     }
 }
 
 // ---- register-form input gradient (fp32 exact) ---------------------------------------------------
 template <int FAM, int GP, int KT>
-int launch_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
+int launch_bwd_input_reg(const LayerArgs& a0, hipStream_t st) {
     constexpr int FPH = (16 * KT) / GP, IC = 2 * FPH;
-    const int nshare = a.groups / a.xmod;
+    const int nshare = a0.groups / a0.xmod;
+    LayerArgs a = a0;
     if (a.I % IC || a.O % 32) return 1;
     if ((a.ldx & 3) || (a.ldy & 3) || (a.O & 3) || (FPH & 3 ? false : ((a.I & 3) != 0)) || ((uintptr_t)a.x & 15) ||
         ((uintptr_t)a.dx & 15) || ((uintptr_t)a.dy & 15) || ((uintptr_t)a.w & 15))
@@ -286,7 +296,11 @@ int launch_bwd_input_reg(const LayerArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * (2 * 16 * WS2_ + (FAM == KV_SINE ? (size_t)nshare * 4 * GP : 0));
     if (FAM == KV_SINE && !a.dparam) return 1;
     const bool shared = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare > 1;
-    dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
+    const long long tiles = (a0.M + BM - 1) / BM;
+    const int nci = a.I / IC;
+    if (FAM != KV_SINE && nci > 1) a.tail_y0 = kv_tail_first_tile(tiles, a.xmod);
+    const long long t1 = a.tail_y0 < tiles ? a.tail_y0 : tiles;
+    dim3 grid((unsigned)a.xmod, (unsigned)(t1 + nci * (tiles - t1)), 1);
     if (shared) {
         if constexpr (kv_shared_basis<FAM>()) {
             hipLaunchKernelGGL((kan_bwd_input_reg_kernel<FAM, GP, KT, true>), grid, dim3(256), lds, st, a);

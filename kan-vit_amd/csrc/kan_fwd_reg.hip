@@ -20,9 +20,10 @@ namespace {
 // scheduling fences pinning "reads of step s+1, then MFMAs of step s": an LDS read takes ~100 cycles from issue to use and
 // the round-1 form (read -> s_waitcnt lgkmcnt(0) -> two MFMAs, the same destination registers every time) left the matrix
 // pipe idle for most of that on every second MFMA (59 % busy in the PMC pass).  GPC == 0 keeps the runtime-GP loop.
-template <int FAM, int NT, int NSH, int ICH, int GPC = 0>
-__global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const LayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// The body takes its block coordinates as arguments: the kernel below hands the LAST row tiles of a shared-basis (NSH = 3) launch
+// to the NSH = 1 body, one projection per work-group (kv_tail_first_tile).
+template <int FAM, int NT, int NSH, int ICH, int GPC>
+__device__ __forceinline__ void kan_fwd_reg_body(const LayerArgs& a, float* __restrict__ smem, const int bx, const int by) {
     constexpr int BN = 32 * NT;
     constexpr int WROW = NSH * BN;
     constexpr int V4 = BN / 4;
@@ -31,10 +32,10 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
     constexpr int TS = 36;                        // staging patch row stride (floats): 16-byte aligned, conflict free
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
     const int ntn = a.O / BN;
-    const int gs = blockIdx.x / ntn;
-    const int n0 = (blockIdx.x - gs * ntn) * BN;
+    const int gs = bx / ntn;
+    const int n0 = (bx - gs * ntn) * BN;
     const int nsets = a.groups / NSH;
-    const long long m0 = (long long)blockIdx.y * BM;
+    const long long m0 = (long long)by * BM;
     const int GP = GPC > 0 ? GPC : a.GP, KC = IC * GP;      // k rows per chunk (even); compile-time in the GPC instantiations (host: a.GP == GPC)
     const int nch = a.I / IC;
     const int WSZ = KC * WROW;
@@ -276,11 +277,43 @@ __global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const Lay
     }
 }
 
+// TAIL (NSH = 3 only): grid rows [tail_y0, ...) are the sub-divided end of the launch -- row tile tail_y0 + t / 3, projection t % 3,
+// run by the one-projection body (it re-evaluates the basis; same k order per output, so the results are bitwise the shared ones).
+template <int FAM, int NT, int NSH, int ICH, int GPC = 0, bool TAIL = false>
+__global__ __launch_bounds__(256, GPC ? 2 : 1) void kan_fwd_reg_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (TAIL) {
+        static_assert(NSH == 3, "the tail hands single projections of a shared-basis launch to the NSH = 1 body");
+        const int ty = (int)blockIdx.y - a.tail_y0;
+        if (ty >= 0) {
+            const int tile = ty / 3, proj = ty - 3 * tile;
+            kan_fwd_reg_body<FAM, NT, 1, ICH, GPC>(a, smem, proj * (int)gridDim.x + (int)blockIdx.x, a.tail_y0 + tile);
+            return;
+        }
+    }
+    kan_fwd_reg_body<FAM, NT, NSH, ICH, GPC>(a, smem, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // ---- register-operand forward (fp32 exact) --------------------------------------------------------
 template <int FAM, int NT, int NSH, int ICH, int GPC = 0>
-int launch_fwd_reg(const LayerArgs& a, size_t lds, hipStream_t st) {
+int launch_fwd_reg(const LayerArgs& a0, size_t lds, hipStream_t st) {
+    const unsigned gx = (unsigned)((a0.groups / NSH) * (a0.O / (32 * NT)));
+    const long long tiles = (a0.M + BM - 1) / BM;
+    if constexpr (NSH == 3 && GPC > 0) {
+        const int t1 = kv_tail_first_tile(tiles, (int)gx);
+        if (t1 < tiles) {
+            LayerArgs a = a0;
+            a.tail_y0 = t1;
+            KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_kernel<FAM, NT, NSH, ICH, GPC, true>));
+            dim3 grid(gx, (unsigned)(t1 + 3 * (tiles - t1)), 1);
+            hipLaunchKernelGGL((kan_fwd_reg_kernel<FAM, NT, NSH, ICH, GPC, true>), grid, dim3(256), lds, st, a);
+            KV_LAUNCH_CHECK("kan_fwd_reg_kernel");
+            return 0;
+        }
+    }
+    const LayerArgs& a = a0;
     KV_ALLOW_LDS(160 * 1024, (kan_fwd_reg_kernel<FAM, NT, NSH, ICH, GPC>));
-    dim3 grid((unsigned)((a.groups / NSH) * (a.O / (32 * NT))), (unsigned)((a.M + BM - 1) / BM), 1);
+    dim3 grid(gx, (unsigned)tiles, 1);
     hipLaunchKernelGGL((kan_fwd_reg_kernel<FAM, NT, NSH, ICH, GPC>), grid, dim3(256), lds, st, a);
     KV_LAUNCH_CHECK("kan_fwd_reg_kernel");
     return 0;

@@ -74,6 +74,7 @@ LayerArgs base_args(const kanvit_layer_desc* d) {
     a.flags = d->flags;
     a.ln = (d->family == KANVIT_RBF && (d->flags & KANVIT_FLAG_FUSED_LN)) ? 1 : 0;
     a.ln_eps = d->ln_eps;
+    a.tail_y0 = 0x7fffffff;             // no sub-divided tail unless a launcher sets one (kv_tail_first_tile)
     return a;
 }
 
@@ -137,9 +138,10 @@ static void kv_config_load() {
     c.bf16_nsh = num("KANVIT_BF16_NSH");
     c.bf16_ic = num("KANVIT_BF16_IC");
     c.bs_bw_bf16 = num("KANVIT_BSPLINE_BW_BF16");
+    c.tail = getenv("KANVIT_TAIL") ? atoi(getenv("KANVIT_TAIL")) : -1;
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d bs_bw_bf16=%d",
-             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid, c.bs_bw_bf16);
+             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d bs_bw_bf16=%d tail=%d",
+             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid, c.bs_bw_bf16, c.tail);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }

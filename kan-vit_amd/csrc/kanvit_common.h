@@ -56,7 +56,8 @@ struct KvConfig {
     int bf16_nsh;        // KANVIT_BF16_NSH        LDS-tile bf16 forward: groups per basis tile (tuning)
     int bf16_ic;         // KANVIT_BF16_IC         LDS-tile bf16 forward: feature chunk cap (tuning)
     int bs_bw_bf16;      // KANVIT_BSPLINE_BW_BF16 B-spline weight gradient in bf16 mode: 0 = default (32-row bf16 register kernel), 1 = LDS-tile bf16 kernel, 2 = exact 16-row kernel (A/B)
-    char text[416];
+    int tail;            // KANVIT_TAIL            row tiles of a q|k|v launch that run as sub-divided work-groups at the end of the grid: -1 = automatic (default), 0 = off, k = k tiles (tuning)
+    char text[432];
 };
 const KvConfig& kv_config();
 
