@@ -16,7 +16,7 @@
 // LDS tiles are [rows][KS] with KS = 32*DT + 1 (odd): conflict free both when lanes walk rows
 // (A operand of q.k^T) and when lanes walk columns (A operand of the second products).  Columns
 // D..32*DT-1 and rows N..NP-1 are zero.
-#include "kanvit_common.h"
+#include "attention_common.h"
 
 #include <type_traits>
 
@@ -67,26 +67,6 @@ __device__ __forceinline__ bf16x8_t kv_acc8(const f32x16& a, int s) {
     return __builtin_bit_cast(bf16x8_t, u);
 }
 
-struct AttnArgs {
-    const float* q;
-    const float* k;
-    const float* v;
-    const float* o;
-    const float* lse_in;
-    const float* d_o;
-    const float* delta_in;
-    float* out;
-    float* lse;
-    float* dq;
-    float* dk;
-    float* dv;
-    float* delta;
-    float* ds;        // [B*H][NP][NP] dS = P*scale*(dP - delta), written by attn_bwd_kv2_kernel<.., DSOUT>, read by attn_bwd_dq_kernel
-    long long qsb, qsh, qsn, ksb, ksh, ksn, vsb, vsh, vsn, osb, osh, osn;
-    int B, H, N, D, causal, nkt, vec;
-    int third;        // backward: the third-form fp32 kernels run (decided once in kanvit_attn_bwd)
-    float scale;
-};
 
 
 // Fill dst[rows][KS] from src rows row0.. (row stride stride_n), zero-padding rows >= N and columns
@@ -536,7 +516,6 @@ __global__ __launch_bounds__(BF ? 256 : 512, 2) void attn_fwd2_kernel(const Attn
 // AGPR <-> VGPR copies of the accumulators (all three measured) -- that is the open item.
 // =============================================================================================
 constexpr int kv_pad4(int d) { return d + 4; }
-constexpr int KV_N_CU = 256;           // MI355X
 // persistent kernels: as many work-groups as are resident at once (LDS-limited), never more than heads
 inline int kv_persistent_grid(int nbh, size_t lds_bytes) {
     const int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
@@ -2241,6 +2220,11 @@ int launch_fwd4(const AttnArgs& a, hipStream_t st) {
 template <int DT, bool BF>
 int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
     if constexpr (!BF && DT == 2) {
+        // 16-row tiles (round 4, csrc/attention16.hip): D = 64, 64 < N <= 204
+        if (!kv_config().attn_v1 && !kv_config().attn_v2 && !kv_config().attn_v3) {
+            const int rc = kv_attn16_fwd(a, st);
+            if (rc <= 0) return rc;
+        }
         // fourth form: D = 64, 64 < N (below, a head is a few tiles and the third form's single fill is cheap), three swizzled
         // images within the 160 KiB, 16-byte aligned rows for the LDS-DMA fills
         if (a.vec && a.D == 64 && a.nkt >= 3 && a.nkt <= 7 && kv_a4_lds(a.N, 64) <= 160 * 1024 && !kv_config().attn_v1 && !kv_config().attn_v2 &&

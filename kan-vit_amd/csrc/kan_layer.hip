@@ -132,6 +132,7 @@ static void kv_config_load() {
     c.attn_v1 = flag("KANVIT_ATTN_V1");
     c.attn_v2 = flag("KANVIT_ATTN_V2");
     c.attn_v3 = flag("KANVIT_ATTN_V3");
+    c.attn_v4 = flag("KANVIT_ATTN_V4");
     c.attn_no_ds = flag("KANVIT_ATTN_NO_DS");
     c.attn_grid = num("KANVIT_ATTN_GRID");
     c.ff_grid = num("KANVIT_FF_GRID");
@@ -140,8 +141,8 @@ static void kv_config_load() {
     c.bs_bw_bf16 = num("KANVIT_BSPLINE_BW_BF16");
     c.tail = getenv("KANVIT_TAIL") ? atoi(getenv("KANVIT_TAIL")) : -1;
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d bs_bw_bf16=%d tail=%d",
-             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid, c.bs_bw_bf16, c.tail);
+             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_v4=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d bs_bw_bf16=%d tail=%d",
+             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_v4, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid, c.bs_bw_bf16, c.tail);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }

@@ -50,6 +50,7 @@ struct KvConfig {
     int attn_v1;         // KANVIT_ATTN_V1         first-form attention kernels
     int attn_v2;         // KANVIT_ATTN_V2         second-form fp32 attention kernels (round 1) instead of the pipelined third form
     int attn_v3;         // KANVIT_ATTN_V3         third-form fp32 attention kernels (round 2) instead of the LDS-DMA ring of the fourth form
+    int attn_v4;         // KANVIT_ATTN_V4         fourth-form fp32 attention kernels (round 3: 32-row tiles) instead of the 16-row-tile kernels of round 4
     int attn_no_ds;      // KANVIT_ATTN_NO_DS      fp32 attention backward without the dS hand-off
     int ff_grid;         // KANVIT_FF_GRID         work-groups of the fused small feed-forward backward (tuning; 0 = default)
     int attn_grid;       // KANVIT_ATTN_GRID       work-groups of the persistent attention kernels (tuning; 0 = one round of resident ones)
