@@ -108,11 +108,23 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
 
     // per-lane LDS offsets (floats, relative to an image) of the two fragment reads of a 16-row tile at row 0:
     //   rows-as-A (K):  row m, logical slots 4 g + i  -> koff[i];   cols-as-A (V): row 4 g + r, logical slot m -> voff[r]
+    // They are re-formed from an opaque copy of the lane index at the start of every phase: as loop invariants hipcc keeps all
+    // eight across the head loop, runs out of registers, spills them -- and a scratch reload waits for the fill just issued.
     int koff[4], voff[4];
+    auto make_koff = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int mm = l & 15, gg = l >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) koff[i] = m * D + 4 * ((4 * g + i) ^ a16_f(m));
+        for (int i = 0; i < 4; ++i) koff[i] = mm * D + 4 * ((4 * gg + i) ^ a16_f(mm));
+    };
+    auto make_voff = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int mm = l & 15, gg = l >> 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) voff[r] = (4 * g + r) * D + 4 * (m ^ a16_f(4 * g + r));
+        for (int r = 0; r < 4; ++r) voff[r] = (4 * gg + r) * D + 4 * (mm ^ a16_f(4 * gg + r));
+    };
     // The ragged last tile reads up to 16 * nt - R rows past its image: the head of the next image, or (third image) of the cut
     // tile's query rows.  Both hold finite numbers -- the whole LDS is zeroed once at kernel entry and only ever receives
     // operand rows, finite partial sums and small counters -- the scores of those rows are masked by SELECT and their
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
         fill(item + 1, a.v + bi * a.vsb + hi * a.vsh, a.vsn);
         store_o();
         const float* K_s = smem + (item % 3) * IMG;
+        make_koff();
         f32x4 sacc[NKT];
         float inv = 0.0f, lse_v = 0.0f;
         if (has_tile) {
@@ -252,26 +265,41 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
                 for (int e = 0; e < 4; ++e) cq[4 * i + e] = u[e];
             }
             const int clim = CAUSAL ? (crow + 1 < N ? crow + 1 : N) : N;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) cacc[jj] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // a quarter is three or four key tiles (13 = 3 + 3 + 3 + 4): tiles 0 and 1 as an interleaved pair, then tile 2 alone or
+            // with tile 3 -- the same two-accumulator interleave as above
+            const float* Kq = K_s + kb0 * 16 * D;
+            auto cut_s = [&](auto j0c, auto twoc) {
+                constexpr int j0 = decltype(j0c)::value;
+                constexpr bool two = decltype(twoc)::value;
+                f32x4 ka[4], kb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ka[i] = *reinterpret_cast<const f32x4*>(Kq + koff[i] + j0 * 16 * D);
+                    if constexpr (two) kb[i] = *reinterpret_cast<const f32x4*>(Kq + koff[i] + (j0 + 1) * 16 * D);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cacc[j0] = a16_mfma(ka[i][e], cq[4 * i + e], cacc[j0]);
+                        if constexpr (two) cacc[j0 + 1] = a16_mfma(kb[i][e], cq[4 * i + e], cacc[j0 + 1]);
+                    }
+            };
+            cut_s(std::integral_constant<int, 0>{}, std::true_type{});
+            if (kb1 - kb0 == 4) cut_s(std::integral_constant<int, 2>{}, std::true_type{});
+            else cut_s(std::integral_constant<int, 2>{}, std::false_type{});
             float mx = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                cacc[jj] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 const int j = kb0 + jj;
-                if (j < kb1) {
-                    f32x4 ka[4];
+                if (CAUSAL || jj >= 2) {              // (the ragged last tile is the third or fourth of its quarter; an absent fourth is all masked)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ka[i] = *reinterpret_cast<const f32x4*>(K_s + koff[i] + j * 16 * D);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) cacc[jj] = a16_mfma(ka[i][e], cq[4 * i + e], cacc[jj]);
-                    if (CAUSAL || j == jl) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) cacc[jj][r] = (16 * j + 4 * g + r >= clim) ? -INFINITY : cacc[jj][r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, cacc[jj][r]);
+                    for (int r = 0; r < 4; ++r) cacc[jj][r] = (j >= kb1 || 16 * j + 4 * g + r >= clim) ? -INFINITY : cacc[jj][r];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, cacc[jj][r]);
             }
             mx = a16_gmax(mx);
             if (g == 0) mx4_s[wave * 16 + m] = mx;
@@ -288,6 +316,7 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
             if (has_tile) load_q(bhn);
         }
         const float* V_s = smem + (item % 3) * IMG;
+        make_voff();
         float* const part_s = smem + ((item + 2) % 3) * IMG;          // the K image of this head is dead: exchange buffer of the cut tile
         if (cutw) {
             // global maximum of the cut tile's queries, probabilities of this quarter, partial O^T over its keys
@@ -298,19 +327,30 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) pacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = kb0 + jj;
-                if (j < kb1) {
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(cacc[jj][r] * sc2 - mxs);
-                        sum += p;
-                        const f32x4 vv = *reinterpret_cast<const f32x4*>(V_s + voff[r] + j * 16 * D);
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) pacc[dt] = a16_mfma(vv[dt], p, pacc[dt]);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(cacc[jj][r] * sc2 - mxs);      // (an absent fourth tile: exp2(-inf) = 0)
+                    cacc[jj][r] = p;
+                    sum += p;
                 }
-            }
+            const float* Vq = V_s + kb0 * 16 * D;
+            auto cut_pv = [&](auto ngc) {            // granules (tile jj, k-step r) of this quarter, reads two granules ahead
+                constexpr int NGC = decltype(ngc)::value;
+                f32x4 fv[3];
+                fv[0] = *reinterpret_cast<const f32x4*>(Vq + voff[0]);
+                fv[1] = *reinterpret_cast<const f32x4*>(Vq + voff[1]);
+                a16_static_for<NGC>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value, jj = t >> 2, r = t & 3;
+                    if constexpr (t + 2 < NGC) fv[(t + 2) % 3] = *reinterpret_cast<const f32x4*>(Vq + voff[(t + 2) & 3] + ((t + 2) >> 2) * 16 * D);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) pacc[dt] = a16_mfma(fv[t % 3][dt], cacc[jj][r], pacc[dt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            if (kb1 - kb0 == 4) cut_pv(std::integral_constant<int, 16>{});
+            else cut_pv(std::integral_constant<int, 12>{});
             sum = a16_gsum(sum);
             if (g == 0) sum4_s[wave * 16 + m] = sum;
 #pragma unroll
@@ -319,7 +359,9 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
                 *reinterpret_cast<f32x4*>(part_s + ((wave * 4 + r) * 64 + lane) * 4) = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) atomicAdd(cnt_s, 1u);
+            // (workgroup scope: hipcc puts s_waitcnt vmcnt(0) in front of an agent-scope atomic -- here that is a wait for this wave's
+            // share of the next head's fill, issued a moment ago)
+            if (lane == 0) __hip_atomic_fetch_add(cnt_s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (has_tile) {
 #pragma unroll
@@ -382,7 +424,7 @@ int launch_fwd16c(const AttnArgs& a, hipStream_t st) {
 }
 
 template <int NKT>
-int launch_fwd16(const AttnArgs& a, hipStream_t st) { return a.causal ? launch_fwd16c<NKT, true>(a, st) : launch_fwd16c<NKT, false>(a, st); }
+int launch_fwd16(const AttnArgs& a, hipStream_t st) { return launch_fwd16c<NKT, false>(a, st); }      // (the causal instantiation of 13 tiles spills: causal launches keep the fourth form)
 
 bool a16_shape_ok(const AttnArgs& a) {
     if (a.D != A16_D || a.N <= 64 || a16_lds_bytes(a.N) > 160 * 1024 || (a.N + 15) / 16 > A16_MAXT || !a.vec) return false;
@@ -395,7 +437,7 @@ bool a16_shape_ok(const AttnArgs& a) {
 }  // namespace
 
 int kv_attn16_fwd(const AttnArgs& a, hipStream_t st) {
-    if (!a16_shape_ok(a) || kv_config().attn_v4) return 1;
+    if (!a16_shape_ok(a) || a.causal || kv_config().attn_v4) return 1;
     if (((uintptr_t)a.out | (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16) return 1;
     switch ((a.N + 15) / 16) {
         case 5: return launch_fwd16<5>(a, st);
