@@ -2557,6 +2557,7 @@ static bool attn_bf16_mode(const kanvit_attn_desc* d) { return (d->flags & KANVI
 // dQ product consumes them as a bf16 operand anyway; needs one query tile per wave of the 512-thread kernels: N <= 256)
 static bool attn_ds_spill(const kanvit_attn_desc* d) {
     if (!(d->D == 32 || d->D == 64) || d->causal || kv_config().attn_no_ds || kv_config().attn_v1) return false;
+    if (kv_attn16_bwd_ok(d)) return false;       // the 16-row-tile backward forms dQ in the same kernel: nothing crosses HBM
     return attn_bf16_mode(d) ? d->N <= 256 : true;
 }
 size_t kanvit_attn_bwd_workspace(const kanvit_attn_desc* d) {
@@ -2591,6 +2592,10 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
         hipLaunchKernelGGL(attn_small_bwd_kernel, dim3((unsigned)((d->B * d->H + 3) / 4)), dim3(256), 0, st, a);
         KV_LAUNCH_CHECK("attn_small_bwd_kernel");
         return 0;
+    }
+    if (kv_attn16_bwd_ok(d) && a.vec) {      // one kernel, five products (csrc/attention16.hip); a refusal (alignment) falls through to the older forms
+        const int rc = kv_attn16_bwd(a, st);
+        if (rc <= 0) return rc;
     }
     const long long rows = (long long)d->B * d->H * d->N;
     // the third-form fp32 kernels form rowsum(dO*O) themselves; every other path reads it from the workspace

@@ -66,6 +66,18 @@ __device__ __forceinline__ void a16_fill(float* __restrict__ img, const float* _
     }
 }
 
+// Counters in LDS, polled.  The pointer is cast to the LDS address space: through a generic pointer hipcc emits a FLAT load, and a
+// flat load is followed by s_waitcnt vmcnt(0) -- every poll would drain the LDS-DMA fills the wave has in flight (measured on the
+// first version of the backward: the 270 us of hand-offs and the 280 us of MFMAs did not overlap at all).
+typedef __attribute__((address_space(3))) unsigned a16_lds_u32;
+__device__ __forceinline__ void a16_wait(const unsigned* c, unsigned target) {
+    const volatile a16_lds_u32* p = (const volatile a16_lds_u32*)c;
+    while (*p < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void a16_signal(unsigned* c, int lane, unsigned n = 1u) {
+    if (lane == 0) __hip_atomic_fetch_add((a16_lds_u32*)c, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ f32x4 a16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // max / sum over the four lane groups (lanes m, m + 16, m + 32, m + 48 hold the same query)
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // (workgroup scope: hipcc puts s_waitcnt vmcnt(0) in front of an agent-scope atomic -- here that is a wait for this wave's
             // share of the next head's fill, issued a moment ago)
-            if (lane == 0) __hip_atomic_fetch_add(cnt_s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            a16_signal(cnt_s, lane);
         }
         if (has_tile) {
 #pragma unroll
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
         if (cutw) {
             // wave q finishes register row r = q of the cut tile: the four partials in quarter order, the total sum, the store
             ++cut_done;
-            while (*reinterpret_cast<volatile unsigned*>(cnt_s) < 4u * cut_done) __builtin_amdgcn_s_sleep(1);
+            a16_wait(cnt_s, 4u * cut_done);
             f32x4 t = *reinterpret_cast<const f32x4*>(part_s + ((0 * 4 + wave) * 64 + lane) * 4);
 #pragma unroll
             for (int q = 1; q < 4; ++q) t += *reinterpret_cast<const f32x4*>(part_s + ((q * 4 + wave) * 64 + lane) * 4);
@@ -434,6 +446,483 @@ bool a16_shape_ok(const AttnArgs& a) {
     return true;
 }
 
+
+// =============================================================================================
+// backward: ONE kernel, all five products, no dS hand-off through HBM
+// =============================================================================================
+// dV = P^T dO, dK = dS^T Q, dQ = dS K with P = exp(S scale - lse), dS = P (dP - delta) scale, S = Q K^T, dP = dO V^T, delta = rowsum(dO O)
+// (utils.py:229-295).  The fourth form ran the first four products in a key-stationary kernel, stored dS ([B H][224][224] fp32:
+// 308 MB written and read back at ViT-B) and formed dQ in a second kernel: 1.92x the algorithmic traffic, 0.46 of the fp32 peak.
+// Here, for 192 < N <= 204 (13 tiles of 16; ViT-B/16 and ViT-S/16: N = 197):
+//   * a work-group (8 waves, two per SIMD, one per CU, persistent over heads) is KEY-stationary: waves 0-4 own two key tiles each
+//     (tiles 2w, 2w + 1), waves 5-7 own tiles 10, 11, 12.  K and V rows of a wave's keys are its MFMA B operands, in registers
+//     for the whole head; dK^T and dV^T accumulate in registers (key on the lane: float4 stores at the end of the head).
+//   * Orientation S = Q.K^T with the QUERY in the accumulator register index: register r of lane group g is query 4 g + r, the
+//     k index of k-step r of the products that contract over queries -- P and dS feed dV^T = dO^T.P and dK^T = Q^T.dS from
+//     registers, exactly as P feeds O^T in the forward.
+//   * The query side STREAMS: a step is one 16-query tile, the same for all waves; its Q, dO and O rows and lse values arrive by
+//     LDS-DMA as a 12 KB slice, two steps ahead, in a ring of four (across head boundaries: nothing is fetched "at" a boundary).
+//     One wave per step forms delta for the next slice from the LDS rows.
+//   * dQ contracts over KEYS, the lane index of dS: each dS tile crosses the LDS once ([16 q][17], 1 KB) and a "unit" -- 16 MFMAs,
+//     dQ^T[d][q] += K^T[d][key].dS^T[key][q] for one (query tile, key tile) pair -- can run on ANY wave.  That is what balances
+//     the SIMDs: thirteen key tiles are 4 + 3 + 3 + 3 on the four SIMDs (waves w and w + 4 share one), and the 13 units of a step
+//     all go to waves 5, 6, 7 -- the ones whose SIMD has only three key tiles: 256 / 261 / 261 / 261 MFMAs per step.
+//     Unit wave u = w - 5 serves key tiles kt = u (mod 3); it keeps THOSE tiles' K rows as a private LDS image (refilled by its
+//     own LDS-DMA at the head boundary: no other wave reads them), works one step behind the producers, and waves 6, 7 hand their
+//     partial sums to wave 5, which adds them in a fixed order and stores dQ: deterministic, no float atomics.
+//   * No barrier after the prologue: every hand-off is a monotonic LDS counter (slice landed / delta formed / slice consumed /
+//     dS tiles written / read / partial written / read) that the waiter polls; rings are one deeper than the data flow needs, so
+//     in steady state nobody waits.
+#ifndef B16_ABLATE
+#define B16_ABLATE 0          // diagnostic builds only (tools/build_variant.sh abl -DB16_ABLATE=n): 1 no S / dP products, 2 no dV / dK products, 4 no unit products,
+                              // 16 no slice fills after the prologue, 32 no waits on counters (timing only: the results are wrong)
+#endif
+#ifdef KANVIT_CLOCK_PROBE
+#ifndef B16_CLK_WAVE
+#define B16_CLK_WAVE 0
+#endif
+// diagnostic build only (tools/clock_probe16.py): phase stamps of one wave of the middle work-group, written to a buffer nothing reads
+__device__ unsigned long long g_b16_clk[16];
+#define B16_CLK_BEGIN() unsigned long long b16_t0 = 0, b16_r0 = 0, b16_tp = 0, b16_ph[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    const bool b16_stamp = (blockIdx.x == gridDim.x / 2) && wave == B16_CLK_WAVE && lane == 0;                      \
+    if (b16_stamp) { b16_t0 = b16_tp = __builtin_amdgcn_s_memtime(); b16_r0 = __builtin_amdgcn_s_memrealtime(); }
+#define B16_CLK_PHASE(i) if (b16_stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long b16_now = __builtin_amdgcn_s_memtime(); b16_ph[i] += b16_now - b16_tp; b16_tp = b16_now; __builtin_amdgcn_sched_barrier(0); }
+#define B16_CLK_END() if (b16_stamp) { g_b16_clk[0] = __builtin_amdgcn_s_memtime() - b16_t0; g_b16_clk[1] = __builtin_amdgcn_s_memrealtime() - b16_r0; \
+    for (int b16_i = 0; b16_i < 14; ++b16_i) g_b16_clk[2 + b16_i] = b16_ph[b16_i]; }
+#else
+#define B16_CLK_BEGIN()
+#define B16_CLK_PHASE(i)
+#define B16_CLK_END()
+#endif
+constexpr int B16_NW = 8;
+constexpr int B16_THREADS = 64 * B16_NW;
+constexpr int B16_NT = 13;                        // key tiles = query tiles = steps per head
+constexpr int B16_SL = 3 * 1024 + 64 + 16;        // slice: Q, dO, O images [16][64], lse (64-float landing zone of a dword DMA), delta
+constexpr int B16_NSL = 4;
+constexpr int B16_DST = 16 * 17;                  // one dS tile, [16 queries][17]
+constexpr int B16_DSS = B16_NT * B16_DST;
+constexpr int B16_NDS = 3;
+constexpr int B16_PART = 2 * 1024;                // partial dQ tiles of waves 6 and 7
+constexpr int B16_NPT = 2;
+constexpr int B16_NCNT = 32;
+enum { BC_READY = 0, BC_DELTA = 4, BC_DONE = 8, BC_DSW = 12, BC_DSR = 15, BC_PW = 18, BC_PR = 20 };
+inline size_t b16_lds_bytes(int N) {
+    return sizeof(float) * ((size_t)a16_rows(N) * A16_D + B16_NDS * B16_DSS + B16_NPT * B16_PART + B16_NSL * B16_SL + B16_NCNT);
+}
+
+__device__ __forceinline__ void b16_wait(const unsigned* c, unsigned target) {
+    if constexpr (!(B16_ABLATE & 32)) a16_wait(c, target);
+}
+__device__ __forceinline__ void b16_signal(unsigned* c, int lane, unsigned n = 1u) { a16_signal(c, lane, n); }
+
+// NTL = key tiles of this wave (2: waves 0-4, which also issue the slice fills; 1: waves 5-7, which also run the dQ units)
+template <int NTL>
+__device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __restrict__ smem, const int lane, const int wave) {
+    constexpr int D = A16_D;
+    constexpr bool UNITS = (NTL == 1);
+    const int N = a.N, nbh = a.B * a.H;
+    const int R = a16_rows(N);
+    float* const kimg = smem;                                         // [R][64] swizzled; over-reads of the last tile land in the dS ring (finite)
+    float* const dsr_s = kimg + R * D;
+    float* const part_s = dsr_s + B16_NDS * B16_DSS;
+    float* const slices = part_s + B16_NPT * B16_PART;
+    unsigned* const cnt = reinterpret_cast<unsigned*>(slices + B16_NSL * B16_SL);
+    const float sc2 = a.scale * KV_LOG2E;
+    const int nh = (nbh - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads of this work-group
+    const int T = B16_NT * nh;                                        // steps
+    const int m = lane & 15, g = lane >> 4;
+    const int kt0 = UNITS ? 10 + (wave - 5) : 2 * wave;               // first key tile of this wave
+    const int u = wave - 5;                                           // unit index (UNITS only)
+
+    auto head_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+
+    // ---- fills ----
+    // slice X = (head k, query tile s): 13 pieces -- Q rows (0-3), dO rows (4-7), O rows (8-11), lse (12); wave w < 5 issues pieces w, w + 5, w + 10
+    auto issue_slice = [&](int k, int sq, int slot) {
+        if constexpr (!UNITS) {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
+            float* sl = slices + slot * B16_SL;
+            const int lq = l >> 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int p = wave + 5 * c;
+                if (p < 12) {
+                    const int which = p >> 2, pp = p & 3;            // 0 Q, 1 dO, 2 O; piece pp = rows 4 pp .. 4 pp + 3 of the tile
+                    int row = 16 * sq + 4 * pp + lq;
+                    const int ls = (l & 15) ^ a16_f(4 * pp + lq);
+                    row = row < N ? row : N - 1;
+                    const float* src = which == 0 ? a.q + bi * a.qsb + hi * a.qsh + row * (int)a.qsn
+                                                  : (which == 1 ? a.d_o : a.o) + bi * a.osb + hi * a.osh + row * (int)a.osn;
+                    __builtin_amdgcn_global_load_lds((a16_glb_ptr)(src + 4 * ls), (a16_lds_ptr)(sl + which * 1024 + pp * 256), 16, 0, 0);
+                } else if (p == 12) {
+                    int row = 16 * sq + l;
+                    row = row < N ? row : N - 1;
+                    __builtin_amdgcn_global_load_lds((a16_glb_ptr)(a.lse_in + (long long)bh * N + row), (a16_lds_ptr)(sl + 3072), 4, 0, 0);
+                }
+            }
+        }
+    };
+    // unit wave: the K rows of its key tiles (kt = u, u + 3, ...) of head k -> private part of the K image
+    auto issue_ktiles = [&](int k) {
+        if constexpr (UNITS) {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
+            const float* kb = a.k + bi * a.ksb + hi * a.ksh;
+            const int lq = l >> 4;
+            for (int kt = u; kt < B16_NT; kt += 3) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int p = 4 * kt + pp;
+                    if (4 * p < R) {
+                        int row = 4 * p + lq;
+                        const int ls = (l & 15) ^ a16_f(4 * pp + lq);
+                        row = row < N ? row : N - 1;
+                        __builtin_amdgcn_global_load_lds((a16_glb_ptr)(kb + row * (int)a.ksn + 4 * ls), (a16_lds_ptr)(kimg + p * 256), 16, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    // delta[q] = sum_d dO[q][d] O[q][d] of a landed slice: 4 lanes per row, the same physical slots of both images
+    auto form_delta = [&](int slot) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const float* sl = slices + slot * B16_SL;
+        const int row = l >> 2, part = l & 3;
+        float dl = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + 1024 + row * D + 16 * part + 4 * j);
+            const f32x4 o4 = *reinterpret_cast<const f32x4*>(sl + 2048 + row * D + 16 * part + 4 * j);
+            dl += d4[0] * o4[0] + d4[1] * o4[1] + d4[2] * o4[2] + d4[3] * o4[3];
+        }
+        dl += __shfl_xor(dl, 1);
+        dl += __shfl_xor(dl, 2);
+        if (part == 0) const_cast<float*>(sl)[3072 + 64 + row] = dl;
+    };
+
+    // ---- this wave's K / V rows (B operands of S and dP): row = key 16 kt + m, values d = 16 g .. 16 g + 15 ----
+    float kf[NTL][16], vf[NTL][16];
+    auto load_kv = [&](int k) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            int key = 16 * (kt0 + t) + (l & 15);
+            key = key < N ? key : N - 1;
+            const float* kp = a.k + bi * a.ksb + hi * a.ksh + key * (int)a.ksn + 16 * (l >> 4);
+            const float* vp = a.v + bi * a.vsb + hi * a.vsh + key * (int)a.vsn + 16 * (l >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + 4 * i);
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kf[t][4 * i + e] = k4[e];
+                    vf[t][4 * i + e] = v4[e];
+                }
+            }
+        }
+    };
+
+    f32x4 dk[NTL][4], dv[NTL][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dk[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                dv[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+    };
+    auto store_dkv = [&](int k) {          // lane = key: registers (dt = 0..3, r') are d = 16 g + 4 r' + dt
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const int key = 16 * (kt0 + t) + (l & 15);
+            if (key < N) {
+                float* kp = a.dk + bi * a.ksb + hi * a.ksh + key * (int)a.ksn + 16 * (l >> 4);
+                float* vp = a.dv + bi * a.vsb + hi * a.vsh + key * (int)a.vsn + 16 * (l >> 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    *reinterpret_cast<f32x4*>(kp + 4 * r) = f32x4{dk[t][0][r], dk[t][1][r], dk[t][2][r], dk[t][3][r]};
+                    *reinterpret_cast<f32x4*>(vp + 4 * r) = f32x4{dv[t][0][r], dv[t][1][r], dv[t][2][r], dv[t][3][r]};
+                }
+            }
+        }
+    };
+
+    // ---------------- prologue (the only barriers) ----------------
+    if constexpr (!UNITS) {
+        issue_slice(0, 0, 0);
+        if (T > 1) issue_slice(0, 1, 1);
+    } else {
+        issue_ktiles(0);
+        __builtin_amdgcn_s_setprio(2);      // the unit waves start a step only when every wave has finished the one before: their MFMAs go first
+    }
+    load_kv(0);
+    zero_acc();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt[BC_READY + 0] = 5u;
+        cnt[BC_READY + 1] = 5u;
+    }
+    __syncthreads();
+
+    // A wave's step is two bursts of MFMAs (S / dP, then dV / dK) and everything else is latency: LDS round trips for counters,
+    // fragments and dS tiles, one after the other.  The first version had 31 s_waitcnt per step -- 6 k cycles per wave and step that
+    // the partner wave of the SIMD, running the same program in phase, did not cover (measured by ablation: 216 us of hand-offs +
+    // 282 us of MFMAs = 466 us with every wait removed).  So: ALL fragment reads of a step are issued up front (the second
+    // products' operands do not depend on P); counters are read together, ahead of their use; a signal is never preceded by a
+    // wait (the LDS executes a wave's instructions in order, so a flag cannot overtake the data it publishes); the slice
+    // bookkeeping sits at the END of a step, when its fill has had a whole step to land.
+    auto peek = [&](const unsigned* c) -> unsigned { return *(const volatile a16_lds_u32*)c; };
+
+    // ---------------- steps ----------------
+    int k = 0, s = 0;                     // head / query tile of step G
+    B16_CLK_BEGIN()
+    for (int G = 0; G <= T; ++G) {
+        B16_CLK_PHASE(7)
+        // ---- dQ units of step G - 1 (waves 5-7) ----
+        if constexpr (UNITS) {
+            if (G >= 1) {
+                const int Y = G - 1, dslot = Y % 3, pslot = Y & 1;
+                const int sy = s == 0 ? B16_NT - 1 : s - 1;                    // its query tile
+                const int ky = s == 0 ? k - 1 : k;                              // its head
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's K tiles (refilled at the head boundary) have landed
+                b16_wait(cnt + BC_DSW + dslot, (unsigned)B16_NT * (unsigned)(Y / 3 + 1));
+                B16_CLK_PHASE(8)
+                int l = lane;
+                asm volatile("" : "+v"(l));
+                const int mm = l & 15, gg = l >> 4;
+                int vo[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vo[r] = (4 * gg + r) * D + 4 * (mm ^ a16_f(4 * gg + r));
+                f32x4 dq[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                const float* dsb = dsr_s + dslot * B16_DSS + mm * 17 + 4 * gg;
+                // operands of unit kt + 3 are read while unit kt multiplies
+                f32x4 fk[2][4];
+                float b[2][4];
+                auto rd_unit = [&](int kt, f32x4 (&xk)[4], float (&xb)[4]) {
+                    const float* Kt = kimg + kt * 16 * D;
+                    const float* dst = dsb + kt * B16_DST;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        xk[ks] = *reinterpret_cast<const f32x4*>(Kt + vo[ks]);      // K[key 16 kt + 4 g + ks][4 m' .. 4 m' + 3]
+                        xb[ks] = dst[ks];                                              // dS[q m''][key 4 g + ks]
+                    }
+                };
+                rd_unit(u, fk[0], b[0]);
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int kt = u + 3 * it;
+                    if (kt < B16_NT) {
+                        if (it + 1 < 5 && kt + 3 < B16_NT) rd_unit(kt + 3, fk[(it + 1) & 1], b[(it + 1) & 1]);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                            for (int dt = 0; dt < 4; ++dt) {
+                                if constexpr (!(B16_ABLATE & 4)) dq[dt] = a16_mfma(fk[it & 1][ks][dt], b[it & 1][ks], dq[dt]);
+                                else dq[dt][0] += fk[it & 1][ks][dt] * b[it & 1][ks];
+                            }
+                    }
+                }
+                B16_CLK_PHASE(9)
+                b16_signal(cnt + BC_DSR + dslot, lane);                          // (issued behind the reads: executes behind them)
+                if (sy == B16_NT - 1 && ky + 1 < nh) issue_ktiles(ky + 1);      // the units of a head are done: its K tiles may be replaced
+                B16_CLK_PHASE(13)
+                float* pp = part_s + pslot * B16_PART;
+                if (u != 0) {
+                    b16_wait(cnt + BC_PR + pslot, (unsigned)(Y >> 1));           // wave 5 is through the partials of step Y - 2
+                    B16_CLK_PHASE(6)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<f32x4*>(pp + (u - 1) * 1024 + (r * 64 + l) * 4) = f32x4{dq[0][r], dq[1][r], dq[2][r], dq[3][r]};
+                    b16_signal(cnt + BC_PW + pslot, lane);
+                } else {
+                    b16_wait(cnt + BC_PW + pslot, 2u * (unsigned)((Y >> 1) + 1));
+                    B16_CLK_PHASE(6)
+                    const int bh = head_of(ky), bi = bh / a.H, hi = bh - bi * a.H;
+                    const int q = 16 * sy + mm;
+                    float* qp = a.dq + bi * a.qsb + hi * a.qsh + q * (int)a.qsn + 16 * gg;
+                    f32x4 p6[4], p7[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        p6[r] = *reinterpret_cast<const f32x4*>(pp + (r * 64 + l) * 4);
+                        p7[r] = *reinterpret_cast<const f32x4*>(pp + 1024 + (r * 64 + l) * 4);
+                    }
+                    b16_signal(cnt + BC_PR + pslot, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x4 t = f32x4{dq[0][r], dq[1][r], dq[2][r], dq[3][r]};
+                        t += p6[r];
+                        t += p7[r];
+                        if (q < N) *reinterpret_cast<f32x4*>(qp + 4 * r) = t;
+                    }
+                }
+            }
+        }
+        if (G == T) break;
+        // ---- delta of slice G, at the START of step G, by one of the fill-issuing waves: the others need it only after their first
+        //      burst of MFMAs (P is formed behind S and dP), so the few hundred cycles this takes delay nobody.  (Formed a step
+        //      ahead it needs the slice two steps ahead, and the ring of four then has no slack for the unit waves, which run a
+        //      step behind: measured, 1.8-2.8 k cycles per step waiting for a slice slot.) ----
+        if constexpr (!UNITS) {
+            if (wave == G % 5) {
+                const int dsl = G & 3;
+                b16_wait(cnt + BC_READY + dsl, 5u * (unsigned)((G >> 2) + 1));
+                form_delta(dsl);
+                b16_signal(cnt + BC_DELTA + dsl, lane);
+            }
+        }
+        B16_CLK_PHASE(0)
+        // ---- the key-stationary step: query tile s of head k against this wave's key tiles ----
+        {
+            const int slot = G & 3, dslot = G % 3;
+            const float* sl = slices + slot * B16_SL;
+            b16_wait(cnt + BC_READY + slot, 5u * (unsigned)((G >> 2) + 1));      // (signalled at the end of step G - 1)
+            B16_CLK_PHASE(1)
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            const int mm = l & 15, gg = l >> 4;
+            int ko[4], vo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ko[i] = mm * D + 4 * ((4 * gg + i) ^ a16_f(mm));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vo[r] = (4 * gg + r) * D + 4 * (mm ^ a16_f(4 * gg + r));
+            // every fragment of the step, now: rows-as-A of Q and dO (first products), the row constants, cols-as-A of dO and Q (second
+            // products: they do not depend on P, so their latency hides under the first burst)
+            f32x4 fq[4], fd[4], fo[4], fq2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fq[i] = *reinterpret_cast<const f32x4*>(sl + ko[i]);
+                fd[i] = *reinterpret_cast<const f32x4*>(sl + 1024 + ko[i]);
+            }
+            const f32x4 ls4 = *reinterpret_cast<const f32x4*>(sl + 3072 + 4 * gg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                fo[r] = *reinterpret_cast<const f32x4*>(sl + 1024 + vo[r]);
+                fq2[r] = *reinterpret_cast<const f32x4*>(sl + vo[r]);
+            }
+            const unsigned dsr_seen = peek(cnt + BC_DSR + dslot);     // (for the dS write at the end of the step)
+            // S[q][key] and dP[q][key]: A = Q / dO rows of the slice (lane = query row), B = this lane's K / V row
+            f32x4 sS[NTL], sP[NTL];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                sS[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                sP[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {
+                        if constexpr (!(B16_ABLATE & 1)) {
+                            sS[t] = a16_mfma(fq[i][e], kf[t][4 * i + e], sS[t]);
+                            sP[t] = a16_mfma(fd[i][e], vf[t][4 * i + e], sP[t]);
+                        } else if (i == 0 && e == 0) {
+                            sS[t][0] += fq[0][0] * kf[t][0] + fq[1][1] + fq[2][2] + fq[3][3];
+                            sP[t][0] += fd[0][0] * vf[t][0] + fd[1][1] + fd[2][2] + fd[3][3];
+                        }
+                    }
+            B16_CLK_PHASE(2)
+            const bool last_s = (s == B16_NT - 1);
+            if (last_s && k + 1 < nh) load_kv(k + 1);                 // the K / V registers are dead until the next head: its rows travel under the second products
+            // P and dS on the accumulator registers: register r is query 16 s + 4 g + r
+            b16_wait(cnt + BC_DELTA + slot, (unsigned)((G >> 2) + 1));
+            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sl + 3072 + 64 + 4 * gg);
+            float pr[NTL][4], ds[NTL][4];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(sS[t][r] * sc2 - ls4[r] * KV_LOG2E);
+                    const bool dead = (last_s && 16 * s + 4 * gg + r >= N) || (kt0 + t == B16_NT - 1 && 16 * (kt0 + t) + mm >= N);
+                    p = dead ? 0.0f : p;
+                    pr[t][r] = p;
+                    ds[t][r] = p * (sP[t][r] - dl4[r]) * a.scale;
+                }
+            B16_CLK_PHASE(3)
+            // dV^T[d][key] += dO^T[d][q] P[q][key], dK^T[d][key] += Q^T[d][q] dS[q][key]: k-step r is queries 4 g + r; one 16-byte read
+            // (row 4 g + r, slot m') feeds the four d-tiles of every key tile of this wave
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {
+                        if constexpr (!(B16_ABLATE & 2)) {
+                            dv[t][dt] = a16_mfma(fo[r][dt], pr[t][r], dv[t][dt]);
+                            dk[t][dt] = a16_mfma(fq2[r][dt], ds[t][r], dk[t][dt]);
+                        } else {
+                            dv[t][dt][0] += fo[r][dt] * pr[t][r];
+                            dk[t][dt][0] += fq2[r][dt] * ds[t][r];
+                        }
+                    }
+            B16_CLK_PHASE(4)
+            b16_signal(cnt + BC_DONE + slot, lane);                   // (behind every read of the slice)
+            // the dS tiles of this step, [q][17]: the unit waves read them a step from now
+            if (G >= B16_NDS && dsr_seen < 3u * (unsigned)(G / 3)) b16_wait(cnt + BC_DSR + dslot, 3u * (unsigned)(G / 3));
+            B16_CLK_PHASE(10)
+            float* dsw = dsr_s + dslot * B16_DSS + (4 * gg) * 17 + mm;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsw[(kt0 + t) * B16_DST + r * 17] = ds[t][r];
+            b16_signal(cnt + BC_DSW + dslot, lane, (unsigned)NTL);
+            if (last_s) {
+                store_dkv(k);
+                zero_acc();
+            }
+        }
+        B16_CLK_PHASE(5)
+        // ---- slice bookkeeping at the END of the step (waves 0-4): slice G + 1 (issued a step ago) has landed; slice G + 2 goes into the
+        //      slot of slice G - 2, which every wave -- the unit waves a step behind included -- has left ----
+        if constexpr (!UNITS) {
+            if (G + 1 < T && G + 1 >= 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                B16_CLK_PHASE(11)
+                b16_signal(cnt + BC_READY + ((G + 1) & 3), lane);
+            }
+            if (G + 2 < T && !(B16_ABLATE & 16)) {
+                const int X = G + 2, slot = X & 3;
+                b16_wait(cnt + BC_DONE + slot, (unsigned)B16_NW * (unsigned)(X >> 2));      // every wave is through step X - 4 = G - 2
+                B16_CLK_PHASE(12)
+                int s2 = s + 2, k2 = k;
+                if (s2 >= B16_NT) { s2 -= B16_NT; ++k2; }
+                issue_slice(k2, s2, slot);
+            }
+        }
+        B16_CLK_PHASE(6)
+        if (++s == B16_NT) { s = 0; ++k; }
+    }
+    B16_CLK_END()
+}
+
+__global__ __launch_bounds__(B16_THREADS) void attn16_bwd_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = a16_rows(a.N) * A16_D + B16_NDS * B16_DSS + B16_NPT * B16_PART + B16_NSL * B16_SL + B16_NCNT;
+    for (int e = tid * 4; e < total; e += B16_THREADS * 4) *reinterpret_cast<f32x4*>(smem + e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    if (wave < 5) attn16_bwd_body<2>(a, smem, lane, wave);
+    else attn16_bwd_body<1>(a, smem, lane, wave);
+}
+
+bool b16_shape_ok(const AttnArgs& a) {
+    return a16_shape_ok(a) && (a.N + 15) / 16 == B16_NT && b16_lds_bytes(a.N) <= 160 * 1024 && !a.causal;
+}
+
 }  // namespace
 
 int kv_attn16_fwd(const AttnArgs& a, hipStream_t st) {
@@ -453,5 +942,27 @@ int kv_attn16_fwd(const AttnArgs& a, hipStream_t st) {
     }
 }
 
-bool kv_attn16_bwd_ok(const kanvit_attn_desc*) { return false; }
-int kv_attn16_bwd(const AttnArgs&, hipStream_t) { return 1; }
+#ifdef KANVIT_CLOCK_PROBE
+extern "C" __attribute__((visibility("default"))) int kanvit_debug_clock16(unsigned long long* out) {      // diagnostic build only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_b16_clk), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
+}
+#endif
+
+bool kv_attn16_bwd_ok(const kanvit_attn_desc* d) {
+    if (!d || kv_config().attn_v4 || kv_config().attn_v1 || kv_config().attn_v2 || kv_config().attn_v3 || kv_config().attn_no_ds) return false;
+    if ((d->flags & KANVIT_FLAG_BF16_MFMA) && !kv_config().no_bf16) return false;
+    return d->D == A16_D && !d->causal && (d->N + 15) / 16 == B16_NT && b16_lds_bytes(d->N) <= 160 * 1024;
+}
+
+int kv_attn16_bwd(const AttnArgs& a, hipStream_t st) {
+    if (!b16_shape_ok(a) || kv_config().attn_v4) return 1;
+    if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.o | (uintptr_t)a.d_o | (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) % 16) return 1;
+    if ((uintptr_t)a.lse_in % 4) return 1;
+    const size_t lds = b16_lds_bytes(a.N);
+    KV_ALLOW_LDS(160 * 1024, attn16_bwd_kernel);
+    const int nbh = a.B * a.H;
+    const int gmax = kv_config().attn_grid > 0 ? kv_config().attn_grid : KV_N_CU;
+    hipLaunchKernelGGL(attn16_bwd_kernel, dim3((unsigned)(nbh < gmax ? nbh : gmax)), dim3(B16_THREADS), lds, st, a);
+    KV_LAUNCH_CHECK("attn16_bwd_kernel");
+    return 0;
+}

@@ -333,6 +333,7 @@ def test_fourth_form_ring_kernels(n, causal, monkeypatch):
         return o.detach().cpu(), qg.grad.cpu(), kg.grad.cpu(), vg.grad.cpu()
 
     monkeypatch.setenv("KANVIT_ATTN_GRID", "5")
+    monkeypatch.setenv("KANVIT_ATTN_V4", "1")          # (since round 4 the default for these shapes is the 16-row-tile form: next test)
     assert "attn_grid=5" in _lib.reload_config()
     try:
         ring = run()
@@ -342,6 +343,7 @@ def test_fourth_form_ring_kernels(n, causal, monkeypatch):
         third = run()
     finally:
         monkeypatch.delenv("KANVIT_ATTN_GRID")
+        monkeypatch.delenv("KANVIT_ATTN_V4")
         monkeypatch.delenv("KANVIT_ATTN_V3", raising=False)
         _lib.reload_config()
     assert all(torch.equal(a, c) for a, c in zip(ring, again))            # no atomics, fixed order: bitwise run to run
@@ -350,6 +352,50 @@ def test_fourth_form_ring_kernels(n, causal, monkeypatch):
         assert close(g, ref)
     for a, c in zip(ring, third):                                        # same mathematics, same summation order per tile
         assert max_err(a, c) < 2e-6 * max(1.0, float(c.abs().max()))
+
+
+@pytest.mark.parametrize("n", [65, 80, 96, 127, 128, 129, 160, 176, 192, 193, 197, 200, 201, 204])
+@pytest.mark.parametrize("bh", [(5, 6), (1, 7), (1, 3)])
+def test_sixteen_row_tile_kernels(n, bh, monkeypatch):
+    """csrc/attention16.hip (round 4): the forward on 16-row tiles for every tile count 5..13 (twelve waves own a tile each, the
+    thirteenth tile is cut into key quarters), and -- for 13 tiles, N = 193..204 -- the one-kernel backward (streamed query slices,
+    dS tiles crossing the LDS, dQ units on the waves of the lighter SIMDs, hand-offs by LDS counters).  Persistent work-groups
+    walk several heads (30 heads on 5 work-groups: every ring and counter wraps), an uneven share (7 on 5) and a single head each
+    (3 on 5: two work-groups idle): against the fp64 oracle, bitwise run to run, and against the fourth-form kernels."""
+    from kanvit import _lib, ops
+    b, h = bh
+    torch.manual_seed(2000 + n + 7 * h)
+    d = 64
+    q, k, v = (torch.randn(b, h, n, d) * 1.2 for _ in range(3))
+    do = torch.randn(b, h, n, d)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_ref, lse_ref = ko.attention_reference(qd, kd, vd, causal=False)
+    o_ref.backward(do.double())
+
+    def run():
+        qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        o = ops.attention(qg, kg, vg, causal=False)
+        o.backward(do.to(DEV))
+        return o.detach().cpu(), qg.grad.cpu(), kg.grad.cpu(), vg.grad.cpu()
+
+    monkeypatch.setenv("KANVIT_ATTN_GRID", "5")
+    assert "attn_grid=5" in _lib.reload_config() and "attn_v4=0" in _lib.active_config()
+    try:
+        new = run()
+        again = run()
+        monkeypatch.setenv("KANVIT_ATTN_V4", "1")
+        assert "attn_v4=1" in _lib.reload_config()
+        fourth = run()
+    finally:
+        monkeypatch.delenv("KANVIT_ATTN_GRID")
+        monkeypatch.delenv("KANVIT_ATTN_V4", raising=False)
+        _lib.reload_config()
+    assert all(torch.equal(a, c) for a, c in zip(new, again))             # counters order the hand-offs, sums have a fixed order: bitwise
+    assert max_err(new[0], o_ref) < 1e-5
+    for g_, ref in zip(new[1:], (qd.grad, kd.grad, vd.grad)):
+        assert close(g_, ref)
+    for a_, c in zip(new, fourth):
+        assert max_err(a_, c) < 4e-6 * max(1.0, float(c.abs().max()))
 
 
 @pytest.mark.parametrize("n,d", [(257, 32), (225, 64), (577, 64), (1025, 16)])
