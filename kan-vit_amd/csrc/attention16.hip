@@ -564,24 +564,26 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
             }
         }
     };
-    // unit wave: the K rows of its key tiles (kt = u, u + 3, ...) of head k -> private part of the K image
-    auto issue_ktiles = [&](int k) {
+    // unit wave u serves key tiles u, u + 3, u + 6, u + 9 and (u = 1: wave 6, not the wave that also reduces and stores) tile 12; it
+    // keeps the K rows of THOSE tiles as its private part of the K image, refilled tile by tile behind the last unit of a head
+    auto unit_tile = [&](int it) -> int { return it < 4 ? u + 3 * it : (u == 1 ? B16_NT - 1 : B16_NT); };
+    auto k_base = [&](int k) -> const float* {
+        const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
+        return a.k + bi * a.ksb + hi * a.ksh;
+    };
+    auto issue_ktile = [&](const float* kb, int kt) {
         if constexpr (UNITS) {
             int l = lane;
             asm volatile("" : "+v"(l));
-            const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
-            const float* kb = a.k + bi * a.ksb + hi * a.ksh;
             const int lq = l >> 4;
-            for (int kt = u; kt < B16_NT; kt += 3) {
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const int p = 4 * kt + pp;
-                    if (4 * p < R) {
-                        int row = 4 * p + lq;
-                        const int ls = (l & 15) ^ a16_f(4 * pp + lq);
-                        row = row < N ? row : N - 1;
-                        __builtin_amdgcn_global_load_lds((a16_glb_ptr)(kb + row * (int)a.ksn + 4 * ls), (a16_lds_ptr)(kimg + p * 256), 16, 0, 0);
-                    }
+            for (int pp = 0; pp < 4; ++pp) {
+                const int p = 4 * kt + pp;
+                if (4 * p < R) {
+                    int row = 4 * p + lq;
+                    const int ls = (l & 15) ^ a16_f(4 * pp + lq);
+                    row = row < N ? row : N - 1;
+                    __builtin_amdgcn_global_load_lds((a16_glb_ptr)(kb + row * (int)a.ksn + 4 * ls), (a16_lds_ptr)(kimg + p * 256), 16, 0, 0);
                 }
             }
         }
@@ -663,7 +665,11 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
         issue_slice(0, 0, 0);
         if (T > 1) issue_slice(0, 1, 1);
     } else {
-        issue_ktiles(0);
+        {
+            const float* kb = k_base(0);
+            for (int it = 0; it < 5; ++it)
+                if (unit_tile(it) < B16_NT) issue_ktile(kb, unit_tile(it));
+        }
         __builtin_amdgcn_s_setprio(2);      // the unit waves start a step only when every wave has finished the one before: their MFMAs go first
     }
     load_kv(0);
@@ -685,6 +691,37 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
     // bookkeeping sits at the END of a step, when its fill has had a whole step to land.
     auto peek = [&](const unsigned* c) -> unsigned { return *(const volatile a16_lds_u32*)c; };
 
+    // Wave 5 sums the three partial dQ tiles of a step and stores them ONE STEP LATE, at the top of its next step, where it would
+    // otherwise wait for the dS tiles: summed right behind its own units it waited for waves 6 / 7 (0.8-1.6 k cycles per step on
+    // the wave every other wave waits for).  Its own partial stays in registers meanwhile.
+    f32x4 dqp[UNITS ? 4 : 1];
+    auto reduce_dq = [&](int Yp) {        // step Yp = (head Yp / 13, query tile Yp % 13)
+        if constexpr (UNITS) {
+            const int pslot = Yp & 1, ky = Yp / B16_NT, sy = Yp - ky * B16_NT;
+            const float* pp = part_s + pslot * B16_PART;
+            b16_wait(cnt + BC_PW + pslot, 2u * (unsigned)((Yp >> 1) + 1));
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            const int bh = head_of(ky), bi = bh / a.H, hi = bh - bi * a.H;
+            const int q = 16 * sy + (l & 15);
+            float* qp = a.dq + bi * a.qsb + hi * a.qsh + q * (int)a.qsn + 16 * (l >> 4);
+            f32x4 p6[4], p7[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p6[r] = *reinterpret_cast<const f32x4*>(pp + (r * 64 + l) * 4);
+                p7[r] = *reinterpret_cast<const f32x4*>(pp + 1024 + (r * 64 + l) * 4);
+            }
+            b16_signal(cnt + BC_PR + pslot, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 t = dqp[r];
+                t += p6[r];
+                t += p7[r];
+                if (q < N) *reinterpret_cast<f32x4*>(qp + 4 * r) = t;
+            }
+        }
+    };
+
     // ---------------- steps ----------------
     int k = 0, s = 0;                     // head / query tile of step G
     B16_CLK_BEGIN()
@@ -692,6 +729,7 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
         B16_CLK_PHASE(7)
         // ---- dQ units of step G - 1 (waves 5-7) ----
         if constexpr (UNITS) {
+            if (G >= 2 && u == 0) reduce_dq(G - 2);
             if (G >= 1) {
                 const int Y = G - 1, dslot = Y % 3, pslot = Y & 1;
                 const int sy = s == 0 ? B16_NT - 1 : s - 1;                    // its query tile
@@ -721,12 +759,14 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                         xb[ks] = dst[ks];                                              // dS[q m''][key 4 g + ks]
                     }
                 };
+                const bool refill = (sy == B16_NT - 1) && (ky + 1 < nh);      // the last units of a head: each tile's K rows are replaced right behind its unit
+                const float* kbn = refill ? k_base(ky + 1) : nullptr;
                 rd_unit(u, fk[0], b[0]);
 #pragma unroll
                 for (int it = 0; it < 5; ++it) {
-                    const int kt = u + 3 * it;
+                    const int kt = unit_tile(it);
                     if (kt < B16_NT) {
-                        if (it + 1 < 5 && kt + 3 < B16_NT) rd_unit(kt + 3, fk[(it + 1) & 1], b[(it + 1) & 1]);
+                        if (it + 1 < 5 && unit_tile(it + 1) < B16_NT) rd_unit(unit_tile(it + 1), fk[(it + 1) & 1], b[(it + 1) & 1]);
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -734,14 +774,14 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                                 if constexpr (!(B16_ABLATE & 4)) dq[dt] = a16_mfma(fk[it & 1][ks][dt], b[it & 1][ks], dq[dt]);
                                 else dq[dt][0] += fk[it & 1][ks][dt] * b[it & 1][ks];
                             }
+                        if (refill) issue_ktile(kbn, kt);      // (its fragments are in registers; the fill lands under the units that follow)
                     }
                 }
                 B16_CLK_PHASE(9)
                 b16_signal(cnt + BC_DSR + dslot, lane);                          // (issued behind the reads: executes behind them)
-                if (sy == B16_NT - 1 && ky + 1 < nh) issue_ktiles(ky + 1);      // the units of a head are done: its K tiles may be replaced
                 B16_CLK_PHASE(13)
-                float* pp = part_s + pslot * B16_PART;
                 if (u != 0) {
+                    float* pp = part_s + pslot * B16_PART;
                     b16_wait(cnt + BC_PR + pslot, (unsigned)(Y >> 1));           // wave 5 is through the partials of step Y - 2
                     B16_CLK_PHASE(6)
 #pragma unroll
@@ -749,25 +789,8 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                         *reinterpret_cast<f32x4*>(pp + (u - 1) * 1024 + (r * 64 + l) * 4) = f32x4{dq[0][r], dq[1][r], dq[2][r], dq[3][r]};
                     b16_signal(cnt + BC_PW + pslot, lane);
                 } else {
-                    b16_wait(cnt + BC_PW + pslot, 2u * (unsigned)((Y >> 1) + 1));
-                    B16_CLK_PHASE(6)
-                    const int bh = head_of(ky), bi = bh / a.H, hi = bh - bi * a.H;
-                    const int q = 16 * sy + mm;
-                    float* qp = a.dq + bi * a.qsb + hi * a.qsh + q * (int)a.qsn + 16 * gg;
-                    f32x4 p6[4], p7[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        p6[r] = *reinterpret_cast<const f32x4*>(pp + (r * 64 + l) * 4);
-                        p7[r] = *reinterpret_cast<const f32x4*>(pp + 1024 + (r * 64 + l) * 4);
-                    }
-                    b16_signal(cnt + BC_PR + pslot, lane);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        f32x4 t = f32x4{dq[0][r], dq[1][r], dq[2][r], dq[3][r]};
-                        t += p6[r];
-                        t += p7[r];
-                        if (q < N) *reinterpret_cast<f32x4*>(qp + 4 * r) = t;
-                    }
+                    for (int r = 0; r < 4; ++r) dqp[r] = f32x4{dq[0][r], dq[1][r], dq[2][r], dq[3][r]};      // summed and stored a step from now (reduce_dq)
                 }
             }
         }
@@ -905,6 +928,9 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
         }
         B16_CLK_PHASE(6)
         if (++s == B16_NT) { s = 0; ++k; }
+    }
+    if constexpr (UNITS) {
+        if (u == 0) reduce_dq(T - 1);
     }
     B16_CLK_END()
 }

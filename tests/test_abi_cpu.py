@@ -106,9 +106,13 @@ def test_descriptor_layout_and_errors(lib):
     a.N, a.D = 197, 63
     assert lib.kanvit_attn_fwd(ctypes.byref(a), None, None, None, None, None, None) == -22
     a.D = 64
-    # rowsum(dO*O) per row (16-byte rounded) + the dS spill of the exact fp32 path: [B*H][NP][NP], NP = 224
+    # rowsum(dO*O) per row (16-byte rounded); N = 197 at D = 64 runs the one-kernel backward of round 4 (csrc/attention16.hip): no dS
+    # hand-off.  Other lengths keep the dS spill of the exact fp32 path: [B*H][NP][NP], NP = N rounded to 32
     delta = (2 * 3 * 197 * 4 + 15) // 16 * 16
-    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta + 2 * 3 * 224 * 224 * 4
+    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta
+    a.N = 160
+    assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == (2 * 3 * 160 * 4 + 15) // 16 * 16 + 2 * 3 * 160 * 160 * 4
+    a.N = 197
     a.flags = 1                                   # bf16 matrix-core mode hands dS over as bf16 (round 3): half the spill
     assert lib.kanvit_attn_bwd_workspace(ctypes.byref(a)) == delta + 2 * 3 * 224 * 224 * 2
     a.N = 300                                     # ... for N <= 256 (one query tile per wave of the dQ kernel); beyond, the recompute kernels
