@@ -461,18 +461,21 @@ bool a16_shape_ok(const AttnArgs& a) {
 //     k index of k-step r of the products that contract over queries -- P and dS feed dV^T = dO^T.P and dK^T = Q^T.dS from
 //     registers, exactly as P feeds O^T in the forward.
 //   * The query side STREAMS: a step is one 16-query tile, the same for all waves; its Q, dO and O rows and lse values arrive by
-//     LDS-DMA as a 12 KB slice, two steps ahead, in a ring of four (across head boundaries: nothing is fetched "at" a boundary).
-//     One wave per step forms delta for the next slice from the LDS rows.
+//     LDS-DMA as a 12 KB slice, four steps ahead, in a ring of six (across head boundaries: nothing is fetched "at" a boundary).
 //   * dQ contracts over KEYS, the lane index of dS: each dS tile crosses the LDS once ([16 q][17], 1 KB) and a "unit" -- 16 MFMAs,
 //     dQ^T[d][q] += K^T[d][key].dS^T[key][q] for one (query tile, key tile) pair -- can run on ANY wave.  That is what balances
 //     the SIMDs: thirteen key tiles are 4 + 3 + 3 + 3 on the four SIMDs (waves w and w + 4 share one), and the 13 units of a step
 //     all go to waves 5, 6, 7 -- the ones whose SIMD has only three key tiles: 256 / 261 / 261 / 261 MFMAs per step.
-//     Unit wave u = w - 5 serves key tiles kt = u (mod 3); it keeps THOSE tiles' K rows as a private LDS image (refilled by its
-//     own LDS-DMA at the head boundary: no other wave reads them), works one step behind the producers, and waves 6, 7 hand their
-//     partial sums to wave 5, which adds them in a fixed order and stores dQ: deterministic, no float atomics.
+//     Unit wave u = w - 5 serves key tiles u, u + 3, u + 6, u + 9 (wave 6 also tile 12) and keeps THOSE tiles' K rows in registers,
+//     in the operand layout of the unit product.  Waves 6, 7 hand their partial sums to wave 5, which adds them in a fixed order
+//     and stores dQ: deterministic, no float atomics.
+//   * The unit waves run TWO steps behind the dS tiles they consume (ring of four), so they never wait for a producer, and they
+//     carry the whole fill protocol (issue, confirm, delta): on the two-tile waves -- which bound the step -- that bookkeeping was
+//     2-3 k cycles per step.  (First version, measured with phase stamps: units one step behind on a ring of three, fills on
+//     waves 0-4, the K tiles of the units in a 51 KB LDS image that left no room for deeper rings: every wave waited 2-5 k cycles
+//     per step for some other wave.)
 //   * No barrier after the prologue: every hand-off is a monotonic LDS counter (slice landed / delta formed / slice consumed /
-//     dS tiles written / read / partial written / read) that the waiter polls; rings are one deeper than the data flow needs, so
-//     in steady state nobody waits.
+//     dS tiles written / read / partial written / read) that the waiter polls.
 #ifndef B16_ABLATE
 #define B16_ABLATE 0          // diagnostic builds only (tools/build_variant.sh abl -DB16_ABLATE=n): 1 no S / dP products, 2 no dV / dK products, 4 no unit products,
                               // 16 no slice fills after the prologue, 32 no waits on counters (timing only: the results are wrong)
@@ -498,52 +501,53 @@ constexpr int B16_NW = 8;
 constexpr int B16_THREADS = 64 * B16_NW;
 constexpr int B16_NT = 13;                        // key tiles = query tiles = steps per head
 constexpr int B16_SL = 3 * 1024 + 64 + 16;        // slice: Q, dO, O images [16][64], lse (64-float landing zone of a dword DMA), delta
-constexpr int B16_NSL = 4;
+constexpr int B16_NSL = 6;                        // slice ring: issued 4 steps ahead (of the unit waves' clock), landed 3 ahead
+constexpr int B16_AHEAD = 4;
 constexpr int B16_DST = 16 * 17;                  // one dS tile, [16 queries][17]
 constexpr int B16_DSS = B16_NT * B16_DST;
-constexpr int B16_NDS = 3;
+constexpr int B16_NDS = 4;                        // dS ring: the units run B16_LAG steps behind
+constexpr int B16_LAG = 2;
 constexpr int B16_PART = 2 * 1024;                // partial dQ tiles of waves 6 and 7
 constexpr int B16_NPT = 2;
 constexpr int B16_NCNT = 32;
-enum { BC_READY = 0, BC_DELTA = 4, BC_DONE = 8, BC_DSW = 12, BC_DSR = 15, BC_PW = 18, BC_PR = 20 };
-inline size_t b16_lds_bytes(int N) {
-    return sizeof(float) * ((size_t)a16_rows(N) * A16_D + B16_NDS * B16_DSS + B16_NPT * B16_PART + B16_NSL * B16_SL + B16_NCNT);
-}
+enum { BC_READY = 0, BC_DELTA = 6, BC_DONE = 12, BC_DSW = 18, BC_DSR = 22, BC_PW = 26, BC_PR = 28 };
+constexpr int b16_lds_floats() { return B16_NDS * B16_DSS + B16_NPT * B16_PART + B16_NSL * B16_SL + B16_NCNT; }
+inline size_t b16_lds_bytes(int) { return sizeof(float) * (size_t)b16_lds_floats(); }
 
 __device__ __forceinline__ void b16_wait(const unsigned* c, unsigned target) {
     if constexpr (!(B16_ABLATE & 32)) a16_wait(c, target);
 }
 __device__ __forceinline__ void b16_signal(unsigned* c, int lane, unsigned n = 1u) { a16_signal(c, lane, n); }
 
-// NTL = key tiles of this wave (2: waves 0-4, which also issue the slice fills; 1: waves 5-7, which also run the dQ units)
+// NTL = key tiles of this wave (2: waves 0-4; 1: waves 5-7, which also run the fills and the dQ units)
 template <int NTL>
 __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __restrict__ smem, const int lane, const int wave) {
     constexpr int D = A16_D;
     constexpr bool UNITS = (NTL == 1);
     const int N = a.N, nbh = a.B * a.H;
-    const int R = a16_rows(N);
-    float* const kimg = smem;                                         // [R][64] swizzled; over-reads of the last tile land in the dS ring (finite)
-    float* const dsr_s = kimg + R * D;
+    float* const dsr_s = smem;
     float* const part_s = dsr_s + B16_NDS * B16_DSS;
     float* const slices = part_s + B16_NPT * B16_PART;
     unsigned* const cnt = reinterpret_cast<unsigned*>(slices + B16_NSL * B16_SL);
     const float sc2 = a.scale * KV_LOG2E;
     const int nh = (nbh - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads of this work-group
     const int T = B16_NT * nh;                                        // steps
-    const int m = lane & 15, g = lane >> 4;
     const int kt0 = UNITS ? 10 + (wave - 5) : 2 * wave;               // first key tile of this wave
     const int u = wave - 5;                                           // unit index (UNITS only)
 
     auto head_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+    auto slot6 = [&](int X) { return X % B16_NSL; };
 
-    // ---- fills ----
-    // slice X = (head k, query tile s): 13 pieces -- Q rows (0-3), dO rows (4-7), O rows (8-11), lse (12); wave w < 5 issues pieces w, w + 5, w + 10
-    auto issue_slice = [&](int k, int sq, int slot) {
+    // ---- fills (waves 0-4) ----
+    // slice X = step X = (head X / 13, query tile X % 13): 13 pieces -- Q rows (0-3), dO rows (4-7), O rows (8-11), lse (12);
+    // wave w < 5 issues pieces w, w + 5, w + 10
+    auto issue_slice = [&](int X) {
         if constexpr (!UNITS) {
             int l = lane;
             asm volatile("" : "+v"(l));
+            const int k = X / B16_NT, sq = X - k * B16_NT;
             const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
-            float* sl = slices + slot * B16_SL;
+            float* sl = slices + slot6(X) * B16_SL;
             const int lq = l >> 4;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -564,35 +568,11 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
             }
         }
     };
-    // unit wave u serves key tiles u, u + 3, u + 6, u + 9 and (u = 1: wave 6, not the wave that also reduces and stores) tile 12; it
-    // keeps the K rows of THOSE tiles as its private part of the K image, refilled tile by tile behind the last unit of a head
-    auto unit_tile = [&](int it) -> int { return it < 4 ? u + 3 * it : (u == 1 ? B16_NT - 1 : B16_NT); };
-    auto k_base = [&](int k) -> const float* {
-        const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
-        return a.k + bi * a.ksb + hi * a.ksh;
-    };
-    auto issue_ktile = [&](const float* kb, int kt) {
-        if constexpr (UNITS) {
-            int l = lane;
-            asm volatile("" : "+v"(l));
-            const int lq = l >> 4;
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int p = 4 * kt + pp;
-                if (4 * p < R) {
-                    int row = 4 * p + lq;
-                    const int ls = (l & 15) ^ a16_f(4 * pp + lq);
-                    row = row < N ? row : N - 1;
-                    __builtin_amdgcn_global_load_lds((a16_glb_ptr)(kb + row * (int)a.ksn + 4 * ls), (a16_lds_ptr)(kimg + p * 256), 16, 0, 0);
-                }
-            }
-        }
-    };
     // delta[q] = sum_d dO[q][d] O[q][d] of a landed slice: 4 lanes per row, the same physical slots of both images
-    auto form_delta = [&](int slot) {
+    auto form_delta = [&](int X) {
         int l = lane;
         asm volatile("" : "+v"(l));
-        const float* sl = slices + slot * B16_SL;
+        float* sl = slices + slot6(X) * B16_SL;
         const int row = l >> 2, part = l & 3;
         float dl = 0.0f;
 #pragma unroll
@@ -603,7 +583,7 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
         }
         dl += __shfl_xor(dl, 1);
         dl += __shfl_xor(dl, 2);
-        if (part == 0) const_cast<float*>(sl)[3072 + 64 + row] = dl;
+        if (part == 0) sl[3072 + 64 + row] = dl;
     };
 
     // ---- this wave's K / V rows (B operands of S and dP): row = key 16 kt + m, values d = 16 g .. 16 g + 15 ----
@@ -626,6 +606,32 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                 for (int e = 0; e < 4; ++e) {
                     kf[t][4 * i + e] = k4[e];
                     vf[t][4 * i + e] = v4[e];
+                }
+            }
+        }
+    };
+    // ---- unit wave: the K rows of the key tiles it serves, as A operands of the unit product: ku[it][4 ks + dt] =
+    //      K[key 16 kt + 4 g + ks][d = 4 m' + dt] (one 16-byte load per k-step) ----
+    auto unit_tile = [&](int it) -> int { return it < 4 ? u + 3 * it : (u == 1 ? B16_NT - 1 : B16_NT); };
+    float ku[UNITS ? 5 : 1][16];
+    auto load_ku = [&](int k) {
+        if constexpr (UNITS) {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            const int bh = head_of(k), bi = bh / a.H, hi = bh - bi * a.H;
+            const float* kb = a.k + bi * a.ksb + hi * a.ksh + 4 * (l & 15);
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int kt = unit_tile(it);
+                if (kt < B16_NT) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        int key = 16 * kt + 4 * (l >> 4) + ks;
+                        key = key < N ? key : N - 1;
+                        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kb + key * (int)a.ksn);
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) ku[it][4 * ks + dt] = k4[dt];
+                    }
                 }
             }
         }
@@ -660,40 +666,31 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
         }
     };
 
-    // ---------------- prologue (the only barriers) ----------------
+    // ---------------- prologue (the only barriers): slices 0 .. AHEAD - 1 land, delta of 0 .. AHEAD - 2 ----------------
     if constexpr (!UNITS) {
-        issue_slice(0, 0, 0);
-        if (T > 1) issue_slice(0, 1, 1);
+        for (int X = 0; X < B16_AHEAD && X < T; ++X) issue_slice(X);
     } else {
-        {
-            const float* kb = k_base(0);
-            for (int it = 0; it < 5; ++it)
-                if (unit_tile(it) < B16_NT) issue_ktile(kb, unit_tile(it));
-        }
-        __builtin_amdgcn_s_setprio(2);      // the unit waves start a step only when every wave has finished the one before: their MFMAs go first
+        load_ku(0);
     }
     load_kv(0);
     zero_acc();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (wave == 0) form_delta(0);
     if (threadIdx.x == 0) {
-        cnt[BC_READY + 0] = 5u;
-        cnt[BC_READY + 1] = 5u;
+        for (int X = 0; X < B16_AHEAD; ++X) cnt[BC_READY + X] = 5u;
+        cnt[BC_DELTA + 0] = 1u;
     }
     __syncthreads();
 
     // A wave's step is two bursts of MFMAs (S / dP, then dV / dK) and everything else is latency: LDS round trips for counters,
-    // fragments and dS tiles, one after the other.  The first version had 31 s_waitcnt per step -- 6 k cycles per wave and step that
-    // the partner wave of the SIMD, running the same program in phase, did not cover (measured by ablation: 216 us of hand-offs +
-    // 282 us of MFMAs = 466 us with every wait removed).  So: ALL fragment reads of a step are issued up front (the second
-    // products' operands do not depend on P); counters are read together, ahead of their use; a signal is never preceded by a
-    // wait (the LDS executes a wave's instructions in order, so a flag cannot overtake the data it publishes); the slice
-    // bookkeeping sits at the END of a step, when its fill has had a whole step to land.
+    // fragments and dS tiles.  ALL fragment reads of a step are issued up front (the second products' operands do not depend on P);
+    // a signal is never preceded by a wait (the LDS executes a wave's instructions in order, so a flag cannot overtake the data it
+    // publishes).
     auto peek = [&](const unsigned* c) -> unsigned { return *(const volatile a16_lds_u32*)c; };
 
-    // Wave 5 sums the three partial dQ tiles of a step and stores them ONE STEP LATE, at the top of its next step, where it would
-    // otherwise wait for the dS tiles: summed right behind its own units it waited for waves 6 / 7 (0.8-1.6 k cycles per step on
-    // the wave every other wave waits for).  Its own partial stays in registers meanwhile.
+    // Wave 5 sums the three partial dQ tiles of a step and stores them one step after its own units of that step, at the top of its
+    // next step: summed right behind the units it waited for waves 6 / 7.  Its own partial stays in registers meanwhile.
     f32x4 dqp[UNITS ? 4 : 1];
     auto reduce_dq = [&](int Yp) {        // step Yp = (head Yp / 13, query tile Yp % 13)
         if constexpr (UNITS) {
@@ -725,60 +722,46 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
     // ---------------- steps ----------------
     int k = 0, s = 0;                     // head / query tile of step G
     B16_CLK_BEGIN()
-    for (int G = 0; G <= T; ++G) {
+    for (int G = 0; G < T + B16_LAG; ++G) {
         B16_CLK_PHASE(7)
-        // ---- dQ units of step G - 1 (waves 5-7) ----
         if constexpr (UNITS) {
-            if (G >= 2 && u == 0) reduce_dq(G - 2);
-            if (G >= 1) {
-                const int Y = G - 1, dslot = Y % 3, pslot = Y & 1;
-                const int sy = s == 0 ? B16_NT - 1 : s - 1;                    // its query tile
-                const int ky = s == 0 ? k - 1 : k;                              // its head
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's K tiles (refilled at the head boundary) have landed
-                b16_wait(cnt + BC_DSW + dslot, (unsigned)B16_NT * (unsigned)(Y / 3 + 1));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // ku / kf / vf of a new head, the dQ stores
+            B16_CLK_PHASE(11)
+            // ---- dQ: wave 5 sums and stores step G - LAG - 1; then the units of step G - LAG ----
+            if (u == 0 && G >= B16_LAG + 1) reduce_dq(G - B16_LAG - 1);
+            if (G >= B16_LAG) {
+                const int Y = G - B16_LAG, dslot = Y % B16_NDS, pslot = Y & 1;
+                const int ky = Y / B16_NT, sy = Y - ky * B16_NT;
+                b16_wait(cnt + BC_DSW + dslot, (unsigned)B16_NT * (unsigned)(Y / B16_NDS + 1));      // (written two steps ago)
                 B16_CLK_PHASE(8)
                 int l = lane;
                 asm volatile("" : "+v"(l));
                 const int mm = l & 15, gg = l >> 4;
-                int vo[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vo[r] = (4 * gg + r) * D + 4 * (mm ^ a16_f(4 * gg + r));
                 f32x4 dq[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 const float* dsb = dsr_s + dslot * B16_DSS + mm * 17 + 4 * gg;
-                // operands of unit kt + 3 are read while unit kt multiplies
-                f32x4 fk[2][4];
-                float b[2][4];
-                auto rd_unit = [&](int kt, f32x4 (&xk)[4], float (&xb)[4]) {
-                    const float* Kt = kimg + kt * 16 * D;
-                    const float* dst = dsb + kt * B16_DST;
+                float b[5][4];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        xk[ks] = *reinterpret_cast<const f32x4*>(Kt + vo[ks]);      // K[key 16 kt + 4 g + ks][4 m' .. 4 m' + 3]
-                        xb[ks] = dst[ks];                                              // dS[q m''][key 4 g + ks]
+                for (int it = 0; it < 5; ++it)
+                    if (unit_tile(it) < B16_NT) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) b[it][ks] = dsb[unit_tile(it) * B16_DST + ks];      // dS[q m''][key 4 g + ks]
                     }
-                };
-                const bool refill = (sy == B16_NT - 1) && (ky + 1 < nh);      // the last units of a head: each tile's K rows are replaced right behind its unit
-                const float* kbn = refill ? k_base(ky + 1) : nullptr;
-                rd_unit(u, fk[0], b[0]);
 #pragma unroll
-                for (int it = 0; it < 5; ++it) {
-                    const int kt = unit_tile(it);
-                    if (kt < B16_NT) {
-                        if (it + 1 < 5 && unit_tile(it + 1) < B16_NT) rd_unit(unit_tile(it + 1), fk[(it + 1) & 1], b[(it + 1) & 1]);
+                for (int it = 0; it < 5; ++it)
+                    if (unit_tile(it) < B16_NT) {
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                             for (int dt = 0; dt < 4; ++dt) {
-                                if constexpr (!(B16_ABLATE & 4)) dq[dt] = a16_mfma(fk[it & 1][ks][dt], b[it & 1][ks], dq[dt]);
-                                else dq[dt][0] += fk[it & 1][ks][dt] * b[it & 1][ks];
+                                if constexpr (!(B16_ABLATE & 4)) dq[dt] = a16_mfma(ku[it][4 * ks + dt], b[it][ks], dq[dt]);
+                                else dq[dt][0] += ku[it][4 * ks + dt] * b[it][ks];
                             }
-                        if (refill) issue_ktile(kbn, kt);      // (its fragments are in registers; the fill lands under the units that follow)
                     }
-                }
                 B16_CLK_PHASE(9)
                 b16_signal(cnt + BC_DSR + dslot, lane);                          // (issued behind the reads: executes behind them)
+                if (sy == B16_NT - 1 && ky + 1 < nh) load_ku(ky + 1);           // the units of a head are done: the next head's K rows
                 B16_CLK_PHASE(13)
                 if (u != 0) {
                     float* pp = part_s + pslot * B16_PART;
@@ -794,25 +777,21 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                 }
             }
         }
-        if (G == T) break;
-        // ---- delta of slice G, at the START of step G, by one of the fill-issuing waves: the others need it only after their first
-        //      burst of MFMAs (P is formed behind S and dP), so the few hundred cycles this takes delay nobody.  (Formed a step
-        //      ahead it needs the slice two steps ahead, and the ring of four then has no slack for the unit waves, which run a
-        //      step behind: measured, 1.8-2.8 k cycles per step waiting for a slice slot.) ----
+        if (G >= T) continue;
+        // ---- delta of slice G + 1 (signalled at the end of step G - 1), by one of the fill-issuing waves: a whole step ahead of its use ----
         if constexpr (!UNITS) {
-            if (wave == G % 5) {
-                const int dsl = G & 3;
-                b16_wait(cnt + BC_READY + dsl, 5u * (unsigned)((G >> 2) + 1));
-                form_delta(dsl);
-                b16_signal(cnt + BC_DELTA + dsl, lane);
+            if (G + 1 < T && wave == (G + 1) % 5) {
+                b16_wait(cnt + BC_READY + slot6(G + 1), 5u * (unsigned)((G + 1) / B16_NSL + 1));
+                form_delta(G + 1);
+                b16_signal(cnt + BC_DELTA + slot6(G + 1), lane);
             }
         }
         B16_CLK_PHASE(0)
         // ---- the key-stationary step: query tile s of head k against this wave's key tiles ----
         {
-            const int slot = G & 3, dslot = G % 3;
+            const int slot = slot6(G), dslot = G % B16_NDS;
             const float* sl = slices + slot * B16_SL;
-            b16_wait(cnt + BC_READY + slot, 5u * (unsigned)((G >> 2) + 1));      // (signalled at the end of step G - 1)
+            b16_wait(cnt + BC_READY + slot, 5u * (unsigned)(G / B16_NSL + 1));      // (signalled steps ago)
             B16_CLK_PHASE(1)
             int l = lane;
             asm volatile("" : "+v"(l));
@@ -862,7 +841,7 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
             const bool last_s = (s == B16_NT - 1);
             if (last_s && k + 1 < nh) load_kv(k + 1);                 // the K / V registers are dead until the next head: its rows travel under the second products
             // P and dS on the accumulator registers: register r is query 16 s + 4 g + r
-            b16_wait(cnt + BC_DELTA + slot, (unsigned)((G >> 2) + 1));
+            b16_wait(cnt + BC_DELTA + slot, (unsigned)(G / B16_NSL + 1));
             const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sl + 3072 + 64 + 4 * gg);
             float pr[NTL][4], ds[NTL][4];
 #pragma unroll
@@ -894,8 +873,8 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                     }
             B16_CLK_PHASE(4)
             b16_signal(cnt + BC_DONE + slot, lane);                   // (behind every read of the slice)
-            // the dS tiles of this step, [q][17]: the unit waves read them a step from now
-            if (G >= B16_NDS && dsr_seen < 3u * (unsigned)(G / 3)) b16_wait(cnt + BC_DSR + dslot, 3u * (unsigned)(G / 3));
+            // the dS tiles of this step, [q][17]: the unit waves read them two steps from now
+            if (G >= B16_NDS && dsr_seen < 3u * (unsigned)(G / B16_NDS)) b16_wait(cnt + BC_DSR + dslot, 3u * (unsigned)(G / B16_NDS));
             B16_CLK_PHASE(10)
             float* dsw = dsr_s + dslot * B16_DSS + (4 * gg) * 17 + mm;
 #pragma unroll
@@ -909,21 +888,19 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
             }
         }
         B16_CLK_PHASE(5)
-        // ---- slice bookkeeping at the END of the step (waves 0-4): slice G + 1 (issued a step ago) has landed; slice G + 2 goes into the
-        //      slot of slice G - 2, which every wave -- the unit waves a step behind included -- has left ----
+        // ---- the fills, at the END of the step (waves 0-4): slice G + AHEAD - 1 (issued a step ago) has landed; slice G + AHEAD goes into
+        //      the slot of slice G + AHEAD - 6, which every wave -- the unit waves, two steps behind, included -- has left ----
         if constexpr (!UNITS) {
-            if (G + 1 < T && G + 1 >= 2) {
+            const int XL = G + B16_AHEAD - 1, XI = G + B16_AHEAD;
+            if (XL >= B16_AHEAD && XL < T) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                B16_CLK_PHASE(11)
-                b16_signal(cnt + BC_READY + ((G + 1) & 3), lane);
+                b16_signal(cnt + BC_READY + slot6(XL), lane);
             }
-            if (G + 2 < T && !(B16_ABLATE & 16)) {
-                const int X = G + 2, slot = X & 3;
-                b16_wait(cnt + BC_DONE + slot, (unsigned)B16_NW * (unsigned)(X >> 2));      // every wave is through step X - 4 = G - 2
+            B16_CLK_PHASE(11)
+            if (XI < T && !(B16_ABLATE & 16)) {
+                if (XI >= B16_NSL) b16_wait(cnt + BC_DONE + slot6(XI), (unsigned)B16_NW * (unsigned)(XI / B16_NSL));      // every wave is through step XI - 6
                 B16_CLK_PHASE(12)
-                int s2 = s + 2, k2 = k;
-                if (s2 >= B16_NT) { s2 -= B16_NT; ++k2; }
-                issue_slice(k2, s2, slot);
+                issue_slice(XI);
             }
         }
         B16_CLK_PHASE(6)
@@ -938,8 +915,7 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
 __global__ __launch_bounds__(B16_THREADS) void attn16_bwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int total = a16_rows(a.N) * A16_D + B16_NDS * B16_DSS + B16_NPT * B16_PART + B16_NSL * B16_SL + B16_NCNT;
-    for (int e = tid * 4; e < total; e += B16_THREADS * 4) *reinterpret_cast<f32x4*>(smem + e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int e = tid * 4; e < b16_lds_floats(); e += B16_THREADS * 4) *reinterpret_cast<f32x4*>(smem + e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
     if (wave < 5) attn16_bwd_body<2>(a, smem, lane, wave);
     else attn16_bwd_body<1>(a, smem, lane, wave);

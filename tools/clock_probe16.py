@@ -22,5 +22,5 @@ torch.cuda.synchronize()
 h.kanvit_debug_clock16(out)
 cyc, ticks = out[0], out[1]
 print(f"stamped wave lived {cyc} shader cycles = {ticks / 100:.1f} us -> in-kernel clock {cyc / (ticks * 10):.3f} GHz; 78 steps")
-names = ["delta (issuers) / units tail: partials, dQ store", "poll slice + delta", "reads + S / dP MFMAs", "exp / dS", "dV / dK MFMAs", "dS tile writes (+ dK / dV store)", "issue slice / units: wait for partials", "loop", "units: wait for the dS tiles", "units: MFMAs", "wait for the dS slot", "wait for the fill (vmcnt)", "wait for the slice slot", "units: DSR signal + K tile fills"]
+names = ["delta (waves 0-4) / units: partial hand-off", "wait for the slice", "reads + S / dP MFMAs", "wait delta + exp / dS", "dV / dK MFMAs", "dS tile writes (+ dK / dV store)", "issue the fill / units: wait for wave 5", "loop", "units: sum + store dQ, wait for the dS tiles", "units: MFMAs", "wait for the dS slot", "wait for the fill (vmcnt)", "wait for the slice slot", "units: DSR signal + next head's K rows"]
 print("    phases (cycles per step): " + ", ".join(f"{n} {out[2 + i] / 78:.0f}" for i, n in enumerate(names)))
