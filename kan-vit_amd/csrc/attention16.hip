@@ -168,6 +168,7 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
         }
     };
 
+    // (Measured, no effect: s_setprio 1 for waves 0-3, which carry a quarter of the cut tile on top of their own.)
     f32x4 oacc[4];
     float o_inv = 0.0f, o_lse = 0.0f;
     int o_bh = -1;                       // head whose output tile waits in oacc (stored after the next phase's barrier)
@@ -208,7 +209,6 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
         for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(qf[e]));      // hipcc's own wait for the Q registers lands here, not behind the next fill
         __builtin_amdgcn_s_barrier();
         fill(item + 1, a.v + bi * a.vsb + hi * a.vsh, a.vsn);
-        store_o();
         const float* K_s = smem + (item % 3) * IMG;
         make_koff();
         f32x4 sacc[NKT];
@@ -266,6 +266,8 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
             inv = 1.0f / sum;
             lse_v = mx * a.scale + logf(sum);
         }
+        store_o();      // the previous head's tile: behind this phase's barrier and fill (in front of the barrier the stores sat in every wave's
+                        // vmcnt(0)), and behind the score products -- the matrix pipe starts right after the barrier
         // the cut tile: this wave's key quarter [kb0, kb1) -- scores now, the maximum over the quarter to the exchange slots
         f32x4 cacc[4];
         if (cutw) {
