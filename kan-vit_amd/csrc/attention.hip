@@ -2233,6 +2233,12 @@ int dispatch_fwd(const AttnArgs& a, hipStream_t st) {
             return launch_fwd4<7>(a, st);
         }
     }
+    if constexpr (BF && DT == 2) {      // bf16 matrix cores on the 16-row-tile structure (round 4): N = 193 .. 204
+        if (!kv_config().attn_v1 && !kv_config().attn_v2 && !kv_config().attn_v3) {
+            const int rc = kv_attn16_fwd_bf16(a, st);
+            if (rc <= 0) return rc;
+        }
+    }
     if constexpr (!BF) {
         if (a.vec && a.D == 32 * DT && ((uintptr_t)a.out % 16 == 0) && !kv_config().attn_v1 && !kv_config().attn_v2) {
             if (a.nkt <= 1) return launch_fwd3<DT, 1>(a, st);

@@ -80,6 +80,21 @@ __device__ __forceinline__ void a16_signal(unsigned* c, int lane, unsigned n = 1
 
 __device__ __forceinline__ f32x4 a16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// bf16 matrix-core mode (KANVIT_FLAG_BF16_MFMA): v_mfma_f32_16x16x32_bf16 -- lane (m = l & 15, g = l >> 4) supplies the eight k-slots
+// 8 g .. 8 g + 7 of row / column m; operands are rounded to bf16 (v_cvt_pk_bf16_f32), products accumulate in fp32, all I/O stays fp32.
+typedef __bf16 a16_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 a16_bf2 __attribute__((ext_vector_type(2)));
+typedef unsigned a16_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned a16_pk(float lo, float hi) {
+    a16_bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ a16_bf8 a16_pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
+    const a16_u4 u = {a16_pk(f0, f1), a16_pk(f2, f3), a16_pk(f4, f5), a16_pk(f6, f7)};
+    return __builtin_bit_cast(a16_bf8, u);
+}
+__device__ __forceinline__ f32x4 a16_mfma_bf(a16_bf8 a, a16_bf8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
 // max / sum over the four lane groups (lanes m, m + 16, m + 32, m + 48 hold the same query)
 __device__ __forceinline__ float a16_gmax(float v) {
     v = fmaxf(v, __shfl_xor(v, 16));
@@ -94,7 +109,11 @@ __device__ __forceinline__ float a16_gsum(float v) {
 // forward
 // =============================================================================================
 // NKT = the number of 16-row tiles of a head, exactly (host: (N + 15) / 16): every tile loop unrolls without a run-time guard
-template <int NKT, bool CAUSAL>
+// BF: the two products on the bf16 matrix cores.  Same images, fills, phases, fragment reads and accumulator layouts; a score tile is two
+// MFMAs (k = 64 head-dimension values, lane group g holds d = 16 g + 8 c + j of MFMA c) instead of sixteen, and P.V contracts two key
+// tiles per MFMA (k-slot j of lane group g is key 4 g + j of the first tile, 4 g + j - 4 of the second: the accumulator registers of
+// the two score tiles as they stand), the four d-tiles' V operands gathered from eight 16-byte reads.
+template <int NKT, bool CAUSAL, bool BF = false>
 __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int D = A16_D;
@@ -212,33 +231,48 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
         const float* K_s = smem + (item % 3) * IMG;
         make_koff();
         f32x4 sacc[NKT];
+        a16_bf8 pbs[BF ? (NKT + 1) / 2 : 1];      // BF: the probabilities of key tiles 2 t, 2 t + 1 as the B operand of their P.V MFMA (packed here: half the registers across the barrier)
         float inv = 0.0f, lse_v = 0.0f;
         if (has_tile) {
 #pragma unroll
             for (int j = 0; j < NKT; ++j) sacc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            // Two key tiles at a time: their MFMAs alternate, so no instruction waits for the accumulator of its predecessor (the
-            // 16x16x4 shape returns its result after 40 cycles and issues every 32).  A granule = one 16-byte K read per tile of
-            // the pair = 8 MFMAs; the reads of granule t + 2 are issued in front of the MFMAs of granule t (ring of three).
-            constexpr int NG = ((NKT + 1) / 2) * 4;
-            f32x4 fa[3], fb[3];
-            auto rd = [&](auto tc, f32x4& xa, f32x4& xb) {
-                constexpr int t = decltype(tc)::value, j = 2 * (t >> 2), i = t & 3;
-                xa = *reinterpret_cast<const f32x4*>(K_s + koff[i] + j * 16 * D);
-                if constexpr (j + 1 < NKT) xb = *reinterpret_cast<const f32x4*>(K_s + koff[i] + (j + 1) * 16 * D);
-            };
-            rd(std::integral_constant<int, 0>{}, fa[0], fb[0]);
-            rd(std::integral_constant<int, 1>{}, fa[1], fb[1]);
-            a16_static_for<NG>([&](auto tc) {
-                constexpr int t = decltype(tc)::value, j = 2 * (t >> 2), i = t & 3;
-                if constexpr (t + 2 < NG) rd(std::integral_constant<int, t + 2>{}, fa[(t + 2) % 3], fb[(t + 2) % 3]);
-                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BF) {
+                const a16_bf8 qb0 = a16_pack8(qf[0], qf[1], qf[2], qf[3], qf[4], qf[5], qf[6], qf[7]);
+                const a16_bf8 qb1 = a16_pack8(qf[8], qf[9], qf[10], qf[11], qf[12], qf[13], qf[14], qf[15]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sacc[j] = a16_mfma(fa[t % 3][e], qf[4 * i + e], sacc[j]);
-                    if constexpr (j + 1 < NKT) sacc[j + 1] = a16_mfma(fb[t % 3][e], qf[4 * i + e], sacc[j + 1]);
+                for (int j = 0; j < NKT; ++j) {
+                    f32x4 ka[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ka[i] = *reinterpret_cast<const f32x4*>(K_s + koff[i] + j * 16 * D);
+                    sacc[j] = a16_mfma_bf(a16_pack8(ka[0][0], ka[0][1], ka[0][2], ka[0][3], ka[1][0], ka[1][1], ka[1][2], ka[1][3]), qb0, sacc[j]);
+                    sacc[j] = a16_mfma_bf(a16_pack8(ka[2][0], ka[2][1], ka[2][2], ka[2][3], ka[3][0], ka[3][1], ka[3][2], ka[3][3]), qb1, sacc[j]);
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            });
+            } else {
+            // Two key tiles at a time: their MFMAs alternate, so no instruction waits for the accumulator of its predecessor (the
+                // 16x16x4 shape returns its result after 40 cycles and issues every 32).  A granule = one 16-byte K read per tile of
+                // the pair = 8 MFMAs; the reads of granule t + 2 are issued in front of the MFMAs of granule t (ring of three).
+                constexpr int NG = ((NKT + 1) / 2) * 4;
+                f32x4 fa[3], fb[3];
+                auto rd = [&](auto tc, f32x4& xa, f32x4& xb) {
+                    constexpr int t = decltype(tc)::value, j = 2 * (t >> 2), i = t & 3;
+                    xa = *reinterpret_cast<const f32x4*>(K_s + koff[i] + j * 16 * D);
+                    if constexpr (j + 1 < NKT) xb = *reinterpret_cast<const f32x4*>(K_s + koff[i] + (j + 1) * 16 * D);
+                };
+                rd(std::integral_constant<int, 0>{}, fa[0], fb[0]);
+                rd(std::integral_constant<int, 1>{}, fa[1], fb[1]);
+                a16_static_for<NG>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value, j = 2 * (t >> 2), i = t & 3;
+                    if constexpr (t + 2 < NG) rd(std::integral_constant<int, t + 2>{}, fa[(t + 2) % 3], fb[(t + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sacc[j] = a16_mfma(fa[t % 3][e], qf[4 * i + e], sacc[j]);
+                        if constexpr (j + 1 < NKT) sacc[j + 1] = a16_mfma(fb[t % 3][e], qf[4 * i + e], sacc[j + 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
             const int lim = CAUSAL ? (qrow + 1 < N ? qrow + 1 : N) : N;
             float mx = -INFINITY;
 #pragma unroll
@@ -265,6 +299,16 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
             sum = a16_gsum(sum);
             inv = 1.0f / sum;
             lse_v = mx * a.scale + logf(sum);
+            if constexpr (BF) {
+#pragma unroll
+                for (int t = 0; t < (NKT + 1) / 2; ++t) {
+                    constexpr int JL = NKT - 1;
+                    const bool pair = 2 * t + 1 < NKT;
+                    const int j1 = pair ? 2 * t + 1 : JL;
+                    pbs[t] = a16_pack8(sacc[2 * t][0], sacc[2 * t][1], sacc[2 * t][2], sacc[2 * t][3], pair ? sacc[j1][0] : 0.0f, pair ? sacc[j1][1] : 0.0f,
+                                       pair ? sacc[j1][2] : 0.0f, pair ? sacc[j1][3] : 0.0f);
+                }
+            }
         }
         store_o();      // the previous head's tile: behind this phase's barrier and fill (in front of the barrier the stores sat in every wave's
                         // vmcnt(0)), and behind the score products -- the matrix pipe starts right after the barrier
@@ -301,9 +345,24 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
                         if constexpr (two) cacc[j0 + 1] = a16_mfma(kb[i][e], cq[4 * i + e], cacc[j0 + 1]);
                     }
             };
-            cut_s(std::integral_constant<int, 0>{}, std::true_type{});
-            if (kb1 - kb0 == 4) cut_s(std::integral_constant<int, 2>{}, std::true_type{});
-            else cut_s(std::integral_constant<int, 2>{}, std::false_type{});
+            if constexpr (BF) {
+                const a16_bf8 qb0 = a16_pack8(cq[0], cq[1], cq[2], cq[3], cq[4], cq[5], cq[6], cq[7]);
+                const a16_bf8 qb1 = a16_pack8(cq[8], cq[9], cq[10], cq[11], cq[12], cq[13], cq[14], cq[15]);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {       // (an absent fourth tile reads the next quarter's first tile: its scores are masked below)
+                    if (jj < 3 || kb1 - kb0 == 4) {
+                        f32x4 ka[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ka[i] = *reinterpret_cast<const f32x4*>(Kq + koff[i] + jj * 16 * D);
+                        cacc[jj] = a16_mfma_bf(a16_pack8(ka[0][0], ka[0][1], ka[0][2], ka[0][3], ka[1][0], ka[1][1], ka[1][2], ka[1][3]), qb0, cacc[jj]);
+                        cacc[jj] = a16_mfma_bf(a16_pack8(ka[2][0], ka[2][1], ka[2][2], ka[2][3], ka[3][0], ka[3][1], ka[3][2], ka[3][3]), qb1, cacc[jj]);
+                    }
+                }
+            } else {
+                cut_s(std::integral_constant<int, 0>{}, std::true_type{});
+                if (kb1 - kb0 == 4) cut_s(std::integral_constant<int, 2>{}, std::true_type{});
+                else cut_s(std::integral_constant<int, 2>{}, std::false_type{});
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -363,8 +422,25 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };
-            if (kb1 - kb0 == 4) cut_pv(std::integral_constant<int, 16>{});
-            else cut_pv(std::integral_constant<int, 12>{});
+            if constexpr (BF) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {          // key tiles 2 t, 2 t + 1 of the quarter (an absent fourth: probabilities 0, finite V rows of the next quarter)
+                    f32x4 v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = *reinterpret_cast<const f32x4*>(Vq + voff[r] + (2 * t) * 16 * D);
+                        v[4 + r] = *reinterpret_cast<const f32x4*>(Vq + voff[r] + (2 * t + 1) * 16 * D);
+                    }
+                    const a16_bf8 pb = a16_pack8(cacc[2 * t][0], cacc[2 * t][1], cacc[2 * t][2], cacc[2 * t][3], cacc[2 * t + 1][0], cacc[2 * t + 1][1],
+                                                 cacc[2 * t + 1][2], cacc[2 * t + 1][3]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        pacc[dt] = a16_mfma_bf(a16_pack8(v[0][dt], v[1][dt], v[2][dt], v[3][dt], v[4][dt], v[5][dt], v[6][dt], v[7][dt]), pb, pacc[dt]);
+                }
+            } else {
+                if (kb1 - kb0 == 4) cut_pv(std::integral_constant<int, 16>{});
+                else cut_pv(std::integral_constant<int, 12>{});
+            }
             sum = a16_gsum(sum);
             if (g == 0) sum4_s[wave * 16 + m] = sum;
 #pragma unroll
@@ -382,23 +458,41 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
             for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             // O^T[d = 4 m' + dt][query] += V[key][4 m' + dt] P[key][query]: k-step r of key tile j is keys 16 j + 4 g + r = accumulator
             // register r of the score tile; one 16-byte V read feeds the four d-tiles
-            // granule = one V read = four MFMAs (the four d-tiles); the read of granule t + 2 in front of the MFMAs of granule t
-            constexpr int NGV = 4 * NKT;
-            f32x4 fv[3];
-            auto rdv = [&](auto tc, f32x4& x) {
-                constexpr int t = decltype(tc)::value, j = t >> 2, r = t & 3;
-                x = *reinterpret_cast<const f32x4*>(V_s + voff[r] + j * 16 * D);
-            };
-            rdv(std::integral_constant<int, 0>{}, fv[0]);
-            rdv(std::integral_constant<int, 1>{}, fv[1]);
-            a16_static_for<NGV>([&](auto tc) {
-                constexpr int t = decltype(tc)::value, j = t >> 2, r = t & 3;
-                if constexpr (t + 2 < NGV) rdv(std::integral_constant<int, t + 2>{}, fv[(t + 2) % 3]);
-                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BF) {
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) oacc[dt] = a16_mfma(fv[t % 3][dt], sacc[j][r], oacc[dt]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                for (int t = 0; t < (NKT + 1) / 2; ++t) {      // key tiles 2 t and 2 t + 1 in one MFMA per d-tile (a missing last partner: probabilities 0)
+                    constexpr int JL = NKT - 1;
+                    const int j1 = (2 * t + 1 < NKT) ? 2 * t + 1 : JL;
+                    f32x4 v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = *reinterpret_cast<const f32x4*>(V_s + voff[r] + (2 * t) * 16 * D);
+                        v[4 + r] = *reinterpret_cast<const f32x4*>(V_s + voff[r] + j1 * 16 * D);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        oacc[dt] = a16_mfma_bf(a16_pack8(v[0][dt], v[1][dt], v[2][dt], v[3][dt], v[4][dt], v[5][dt], v[6][dt], v[7][dt]), pbs[t], oacc[dt]);
+                    __builtin_amdgcn_sched_barrier(0);      // (without it hipcc hoists the reads of several pairs and spills)
+                }
+            } else {
+            // granule = one V read = four MFMAs (the four d-tiles); the read of granule t + 2 in front of the MFMAs of granule t
+                constexpr int NGV = 4 * NKT;
+                f32x4 fv[3];
+                auto rdv = [&](auto tc, f32x4& x) {
+                    constexpr int t = decltype(tc)::value, j = t >> 2, r = t & 3;
+                    x = *reinterpret_cast<const f32x4*>(V_s + voff[r] + j * 16 * D);
+                };
+                rdv(std::integral_constant<int, 0>{}, fv[0]);
+                rdv(std::integral_constant<int, 1>{}, fv[1]);
+                a16_static_for<NGV>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value, j = t >> 2, r = t & 3;
+                    if constexpr (t + 2 < NGV) rdv(std::integral_constant<int, t + 2>{}, fv[(t + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) oacc[dt] = a16_mfma(fv[t % 3][dt], sacc[j][r], oacc[dt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
             o_bh = bh;
             o_inv = inv;
             o_lse = lse_v;
@@ -426,19 +520,19 @@ __global__ __launch_bounds__(A16_THREADS) void attn16_fwd_kernel(const AttnArgs 
     store_o();
 }
 
-template <int NKT, bool CAUSAL>
+template <int NKT, bool CAUSAL, bool BF>
 int launch_fwd16c(const AttnArgs& a, hipStream_t st) {
     const size_t lds = a16_lds_bytes(a.N);
-    KV_ALLOW_LDS(160 * 1024, (attn16_fwd_kernel<NKT, CAUSAL>));
+    KV_ALLOW_LDS(160 * 1024, (attn16_fwd_kernel<NKT, CAUSAL, BF>));
     const int nbh = a.B * a.H;
     const int gmax = kv_config().attn_grid > 0 ? kv_config().attn_grid : KV_N_CU;      // one work-group per CU (the three images fill its LDS)
-    hipLaunchKernelGGL((attn16_fwd_kernel<NKT, CAUSAL>), dim3((unsigned)(nbh < gmax ? nbh : gmax)), dim3(A16_THREADS), lds, st, a);
+    hipLaunchKernelGGL((attn16_fwd_kernel<NKT, CAUSAL, BF>), dim3((unsigned)(nbh < gmax ? nbh : gmax)), dim3(A16_THREADS), lds, st, a);
     KV_LAUNCH_CHECK("attn16_fwd_kernel");
     return 0;
 }
 
 template <int NKT>
-int launch_fwd16(const AttnArgs& a, hipStream_t st) { return launch_fwd16c<NKT, false>(a, st); }      // (the causal instantiation of 13 tiles spills: causal launches keep the fourth form)
+int launch_fwd16(const AttnArgs& a, hipStream_t st) { return launch_fwd16c<NKT, false, false>(a, st); }      // (the causal instantiation of 13 tiles spills: causal launches keep the fourth form)
 
 bool a16_shape_ok(const AttnArgs& a) {
     if (a.D != A16_D || a.N <= 64 || a16_lds_bytes(a.N) > 160 * 1024 || (a.N + 15) / 16 > A16_MAXT || !a.vec) return false;
@@ -951,6 +1045,13 @@ extern "C" __attribute__((visibility("default"))) int kanvit_debug_clock16(unsig
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_b16_clk), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -5;
 }
 #endif
+
+// the same forward with its two products on the bf16 matrix cores (KANVIT_FLAG_BF16_MFMA), 13 tiles only (N = 193 .. 204)
+int kv_attn16_fwd_bf16(const AttnArgs& a, hipStream_t st) {
+    if (!a16_shape_ok(a) || a.causal || kv_config().attn_v4 || (a.N + 15) / 16 != A16_MAXT) return 1;
+    if (((uintptr_t)a.out | (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16) return 1;
+    return launch_fwd16c<A16_MAXT, false, true>(a, st);
+}
 
 bool kv_attn16_bwd_ok(const kanvit_attn_desc* d) {
     if (!d || kv_config().attn_v4 || kv_config().attn_v1 || kv_config().attn_v2 || kv_config().attn_v3 || kv_config().attn_no_ds) return false;

@@ -311,7 +311,9 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
 // (Measured and removed, round 4: ChebyKAN's q|k|v launch on this kernel -- all five values x 12 tiles of 16 columns in 240 accumulators,
 // one wave per SIMD, 60 MFMAs of 32 cycles per evaluation of tanh + the recurrence instead of 15 of 64: 379 against 368 us for the 32-row
 // form on one box.  The ISA says why: the 32-row loop carries 54 vector instructions per four tokens and the 16-row loop 67 -- the basis
-// evaluation is a minority of them, and the twelve dY streams add more ring moves and selects than the halved evaluations remove.)
+// evaluation is a minority of them, and the twelve dY streams add more ring moves and selects than the halved evaluations remove.  Five
+// values x SIX tiles of 16 at two waves per SIMD -- the same work per evaluation as the 32-row form, a partner wave to cover the
+// latencies -- was measured too: 372-374 against 360-364 us, same box.)
 template <int FAM, int GP, int JC, int NC>
 __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const LayerArgs a, int nfb, int nos, int tiles_per_bg, int shared, int nbg) {
     constexpr int NJC = (GP + JC - 1) / JC;
