@@ -23,7 +23,7 @@ def load(path, counter):
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         name = re.sub(r"^void ", "", name)
         name = re.sub(r"\(.*", "", name)
-        if not name.startswith(("kan_", "attn_")):
+        if not name.startswith(("kan_", "attn_", "attn16_")):
             continue
         k = (name, r.get("Grid_Size", "?"))
         agg[k][0] += 1
@@ -39,10 +39,10 @@ def classify(agg):
     for (k, grid), (n, v) in agg.items():
         grouped = n >= 6 * lo
         pre = "qkv" if grouped else "layer"
-        if k.startswith("attn_fwd"):
+        if k.startswith(("attn_fwd", "attn16_fwd")):
             op, main = "attn_fwd", True
-        elif k.startswith("attn_"):
-            op, main = "attn_bwd", k.startswith("attn_bwd_kv")
+        elif k.startswith(("attn_", "attn16_")):         # (round 4: attn16_bwd_kernel is the whole backward)
+            op, main = "attn_bwd", k.startswith(("attn_bwd_kv", "attn16_bwd"))
         elif k.startswith(("kan_fwd", "kan_pack_w_fwd")):
             op, main = pre + "_fwd", k.startswith("kan_fwd")
         elif k.startswith(("kan_bwd_input", "kan_pack_w_bwd")):

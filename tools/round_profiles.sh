@@ -18,8 +18,8 @@ echo "profiles done"
 fi
 if [ "$STAGE" = all ] || [ "$STAGE" = 2 ]; then
 # 2. SQ counters of the custom kernels (one MSA block, forward + backward), fp32 and bf16
-bash tools/pmc_kernel.sh "kan_|attn_" bwd fp32 3 > $O/sq_pmc_fp32.txt 2>&1 || { echo "sq fp32 failed"; tail -5 $O/sq_pmc_fp32.txt; exit 1; }
-bash tools/pmc_kernel.sh "kan_|attn_" bwd amp 3 > $O/sq_pmc_bf16.txt 2>&1 || { echo "sq bf16 failed"; tail -5 $O/sq_pmc_bf16.txt; exit 1; }
+bash tools/pmc_kernel.sh "kan_|attn" bwd fp32 3 > $O/sq_pmc_fp32.txt 2>&1 || { echo "sq fp32 failed"; tail -5 $O/sq_pmc_fp32.txt; exit 1; }
+bash tools/pmc_kernel.sh "kan_|attn" bwd amp 3 > $O/sq_pmc_bf16.txt 2>&1 || { echo "sq bf16 failed"; tail -5 $O/sq_pmc_bf16.txt; exit 1; }
 bash tools/pmc_kernel.sh "kan_" bwd fp32 3 efficientkan > $O/sq_pmc_efficientkan_fp32.txt 2>&1 || { echo "sq efficientkan failed"; exit 1; }
 bash tools/pmc_kernel.sh "kan_" bwd amp 3 fast vits > $O/sq_pmc_fast_vits_bf16.txt 2>&1 || { echo "sq fast failed"; exit 1; }
 echo "sq done"
