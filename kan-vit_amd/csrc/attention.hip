@@ -2603,6 +2603,10 @@ int kanvit_attn_bwd(const kanvit_attn_desc* d, const float* q, const float* k, c
         const int rc = kv_attn16_bwd(a, st);
         if (rc <= 0) return rc;
     }
+    if (attn_bf16_mode(d) && a.vec && !kv_config().attn_v1 && !kv_config().attn_v2 && !kv_config().attn_v3 && !kv_config().attn_no_ds) {      // the same kernel on the bf16 matrix cores
+        const int rc = kv_attn16_bwd_bf16(a, st);
+        if (rc <= 0) return rc;
+    }
     const long long rows = (long long)d->B * d->H * d->N;
     // the third-form fp32 kernels form rowsum(dO*O) themselves; every other path reads it from the workspace
     const size_t lds3 = sizeof(float) * ((size_t)2 * a.nkt * 32 * kv_pad4(d->D) + 2 * (size_t)a.nkt * 32);

@@ -94,6 +94,15 @@ __device__ __forceinline__ a16_bf8 a16_pack8(float f0, float f1, float f2, float
     return __builtin_bit_cast(a16_bf8, u);
 }
 __device__ __forceinline__ f32x4 a16_mfma_bf(a16_bf8 a, a16_bf8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// v_mfma_f32_16x16x16_bf16: k = 16, lane group g supplies k-slots 4 g .. 4 g + 3 (the products of the backward that contract over the 16
+// queries of a step or the 16 keys of a tile)
+typedef short a16_s4 __attribute__((ext_vector_type(4)));
+typedef unsigned a16_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ a16_s4 a16_pack4(float f0, float f1, float f2, float f3) {
+    const a16_u2 u = {a16_pk(f0, f1), a16_pk(f2, f3)};
+    return __builtin_bit_cast(a16_s4, u);
+}
+__device__ __forceinline__ f32x4 a16_mfma_bf4(a16_s4 a, a16_s4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
 // max / sum over the four lane groups (lanes m, m + 16, m + 32, m + 48 hold the same query)
 __device__ __forceinline__ float a16_gmax(float v) {
@@ -616,7 +625,10 @@ __device__ __forceinline__ void b16_wait(const unsigned* c, unsigned target) {
 __device__ __forceinline__ void b16_signal(unsigned* c, int lane, unsigned n = 1u) { a16_signal(c, lane, n); }
 
 // NTL = key tiles of this wave (2: waves 0-4; 1: waves 5-7, which also run the fills and the dQ units)
-template <int NTL>
+// BF: the five products on the bf16 matrix cores (KANVIT_FLAG_BF16_MFMA): S and dP are two v_mfma_f32_16x16x32_bf16 per tile, the three
+// products that contract over 16 queries / 16 keys one v_mfma_f32_16x16x16_bf16 per d-tile; Q, K, V, dO, P and dS are rounded to bf16 as
+// operands, everything accumulates in fp32, delta and the dS tiles in the LDS stay fp32.  Same slices, rings, counters and waves.
+template <int NTL, bool BF>
 __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __restrict__ smem, const int lane, const int wave) {
     constexpr int D = A16_D;
     constexpr bool UNITS = (NTL == 1);
@@ -684,6 +696,7 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
 
     // ---- this wave's K / V rows (B operands of S and dP): row = key 16 kt + m, values d = 16 g .. 16 g + 15 ----
     float kf[NTL][16], vf[NTL][16];
+    a16_bf8 kfb[NTL][2], vfb[NTL][2];          // BF: the same rows as MFMA operands, d = 16 g + 8 c + j in element j of [c]
     auto load_kv = [&](int k) {
         int l = lane;
         asm volatile("" : "+v"(l));
@@ -704,12 +717,20 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                     vf[t][4 * i + e] = v4[e];
                 }
             }
+            if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    kfb[t][c] = a16_pack8(kf[t][8 * c], kf[t][8 * c + 1], kf[t][8 * c + 2], kf[t][8 * c + 3], kf[t][8 * c + 4], kf[t][8 * c + 5], kf[t][8 * c + 6], kf[t][8 * c + 7]);
+                    vfb[t][c] = a16_pack8(vf[t][8 * c], vf[t][8 * c + 1], vf[t][8 * c + 2], vf[t][8 * c + 3], vf[t][8 * c + 4], vf[t][8 * c + 5], vf[t][8 * c + 6], vf[t][8 * c + 7]);
+                }
+            }
         }
     };
     // ---- unit wave: the K rows of the key tiles it serves, as A operands of the unit product: ku[it][4 ks + dt] =
     //      K[key 16 kt + 4 g + ks][d = 4 m' + dt] (one 16-byte load per k-step) ----
     auto unit_tile = [&](int it) -> int { return it < 4 ? u + 3 * it : (u == 1 ? B16_NT - 1 : B16_NT); };
     float ku[UNITS ? 5 : 1][16];
+    a16_s4 kub[UNITS ? 5 : 1][4];              // BF: [it][dt] = the four k-steps ks of d-tile dt
     auto load_ku = [&](int k) {
         if constexpr (UNITS) {
             int l = lane;
@@ -727,6 +748,10 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                         const f32x4 k4 = *reinterpret_cast<const f32x4*>(kb + key * (int)a.ksn);
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt) ku[it][4 * ks + dt] = k4[dt];
+                    }
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) kub[it][dt] = a16_pack4(ku[it][dt], ku[it][4 + dt], ku[it][8 + dt], ku[it][12 + dt]);
                     }
                 }
             }
@@ -847,13 +872,19 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
 #pragma unroll
                 for (int it = 0; it < 5; ++it)
                     if (unit_tile(it) < B16_NT) {
+                        if constexpr (BF) {
+                            const a16_s4 bb = a16_pack4(b[it][0], b[it][1], b[it][2], b[it][3]);
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
+                            for (int dt = 0; dt < 4; ++dt) dq[dt] = a16_mfma_bf4(kub[it][dt], bb, dq[dt]);
+                        } else {
 #pragma unroll
-                            for (int dt = 0; dt < 4; ++dt) {
-                                if constexpr (!(B16_ABLATE & 4)) dq[dt] = a16_mfma(ku[it][4 * ks + dt], b[it][ks], dq[dt]);
-                                else dq[dt][0] += ku[it][4 * ks + dt] * b[it][ks];
-                            }
+                            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                                for (int dt = 0; dt < 4; ++dt) {
+                                    if constexpr (!(B16_ABLATE & 4)) dq[dt] = a16_mfma(ku[it][4 * ks + dt], b[it][ks], dq[dt]);
+                                    else dq[dt][0] += ku[it][4 * ks + dt] * b[it][ks];
+                                }
+                        }
                     }
                 B16_CLK_PHASE(9)
                 b16_signal(cnt + BC_DSR + dslot, lane);                          // (issued behind the reads: executes behind them)
@@ -919,6 +950,18 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
                 sS[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 sP[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
+            if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const a16_bf8 aq = a16_pack8(fq[2 * c][0], fq[2 * c][1], fq[2 * c][2], fq[2 * c][3], fq[2 * c + 1][0], fq[2 * c + 1][1], fq[2 * c + 1][2], fq[2 * c + 1][3]);
+                    const a16_bf8 ad = a16_pack8(fd[2 * c][0], fd[2 * c][1], fd[2 * c][2], fd[2 * c][3], fd[2 * c + 1][0], fd[2 * c + 1][1], fd[2 * c + 1][2], fd[2 * c + 1][3]);
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {
+                        sS[t] = a16_mfma_bf(aq, kfb[t][c], sS[t]);
+                        sP[t] = a16_mfma_bf(ad, vfb[t][c], sP[t]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -953,6 +996,24 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
             B16_CLK_PHASE(3)
             // dV^T[d][key] += dO^T[d][q] P[q][key], dK^T[d][key] += Q^T[d][q] dS[q][key]: k-step r is queries 4 g + r; one 16-byte read
             // (row 4 g + r, slot m') feeds the four d-tiles of every key tile of this wave
+            if constexpr (BF) {
+                a16_s4 pb[NTL], db[NTL];
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    pb[t] = a16_pack4(pr[t][0], pr[t][1], pr[t][2], pr[t][3]);
+                    db[t] = a16_pack4(ds[t][0], ds[t][1], ds[t][2], ds[t][3]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const a16_s4 ao = a16_pack4(fo[0][dt], fo[1][dt], fo[2][dt], fo[3][dt]);
+                    const a16_s4 aq2 = a16_pack4(fq2[0][dt], fq2[1][dt], fq2[2][dt], fq2[3][dt]);
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {
+                        dv[t][dt] = a16_mfma_bf4(ao, pb[t], dv[t][dt]);
+                        dk[t][dt] = a16_mfma_bf4(aq2, db[t], dk[t][dt]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1008,13 +1069,14 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
     B16_CLK_END()
 }
 
+template <bool BF>
 __global__ __launch_bounds__(B16_THREADS) void attn16_bwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid * 4; e < b16_lds_floats(); e += B16_THREADS * 4) *reinterpret_cast<f32x4*>(smem + e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
-    if (wave < 5) attn16_bwd_body<2>(a, smem, lane, wave);
-    else attn16_bwd_body<1>(a, smem, lane, wave);
+    if (wave < 5) attn16_bwd_body<2, BF>(a, smem, lane, wave);
+    else attn16_bwd_body<1, BF>(a, smem, lane, wave);
 }
 
 bool b16_shape_ok(const AttnArgs& a) {
@@ -1059,15 +1121,18 @@ bool kv_attn16_bwd_ok(const kanvit_attn_desc* d) {
     return d->D == A16_D && !d->causal && (d->N + 15) / 16 == B16_NT && b16_lds_bytes(d->N) <= 160 * 1024;
 }
 
-int kv_attn16_bwd(const AttnArgs& a, hipStream_t st) {
+template <bool BF>
+static int launch_bwd16(const AttnArgs& a, hipStream_t st) {
     if (!b16_shape_ok(a) || kv_config().attn_v4) return 1;
     if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.o | (uintptr_t)a.d_o | (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) % 16) return 1;
     if ((uintptr_t)a.lse_in % 4) return 1;
     const size_t lds = b16_lds_bytes(a.N);
-    KV_ALLOW_LDS(160 * 1024, attn16_bwd_kernel);
+    KV_ALLOW_LDS(160 * 1024, attn16_bwd_kernel<BF>);
     const int nbh = a.B * a.H;
     const int gmax = kv_config().attn_grid > 0 ? kv_config().attn_grid : KV_N_CU;
-    hipLaunchKernelGGL(attn16_bwd_kernel, dim3((unsigned)(nbh < gmax ? nbh : gmax)), dim3(B16_THREADS), lds, st, a);
+    hipLaunchKernelGGL(attn16_bwd_kernel<BF>, dim3((unsigned)(nbh < gmax ? nbh : gmax)), dim3(B16_THREADS), lds, st, a);
     KV_LAUNCH_CHECK("attn16_bwd_kernel");
     return 0;
 }
+int kv_attn16_bwd(const AttnArgs& a, hipStream_t st) { return launch_bwd16<false>(a, st); }
+int kv_attn16_bwd_bf16(const AttnArgs& a, hipStream_t st) { return launch_bwd16<true>(a, st); }

@@ -32,5 +32,6 @@ constexpr float KV_LOG2E = 1.4426950408889634f;
 int kv_attn16_fwd(const AttnArgs& a, hipStream_t st);
 int kv_attn16_bwd(const AttnArgs& a, hipStream_t st);
 int kv_attn16_fwd_bf16(const AttnArgs& a, hipStream_t st);      // KANVIT_FLAG_BF16_MFMA
+int kv_attn16_bwd_bf16(const AttnArgs& a, hipStream_t st);
 // the exact-fp32 backward of this shape runs kv_attn16_bwd and needs no dS hand-off in the workspace (host-side shape test only)
 bool kv_attn16_bwd_ok(const kanvit_attn_desc* d);

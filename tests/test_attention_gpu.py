@@ -111,7 +111,8 @@ def test_bf16_mfma_attention_close_to_fp32(n, d):
 
 @pytest.mark.parametrize("n,d", [(50, 32), (65, 64), (197, 64), (224, 64), (256, 32)])
 def test_bf16_ds_handoff_equals_recomputation(n, d, monkeypatch):
-    """bf16 mode, backward: the key-stationary kernel hands dS to the dQ kernel as bf16 (one product, attn_bwd_dq_bf16_kernel)
+    """bf16 mode, backward (the two-kernel form; at (197, 64) the default is the one-kernel form of round 4, checked against both here):
+    the key-stationary kernel hands dS to the dQ kernel as bf16 (one product, attn_bwd_dq_bf16_kernel)
     instead of the dQ kernel recomputing S, dP and the exponentials (KANVIT_ATTN_NO_DS=1: attn_bwd_q2_kernel).  dK / dV come from
     the same kernel either way -> bitwise equal; dQ is the same product of the same bf16-rounded factors up to where the rounding
     of dS happens -> both within the bf16 bound of the exact fp32 gradient, and close to each other."""
@@ -137,7 +138,13 @@ def test_bf16_ds_handoff_equals_recomputation(n, d, monkeypatch):
     recomputed = run(True)
     monkeypatch.delenv("KANVIT_ATTN_NO_DS", raising=False)
     _lib.reload_config()
-    assert torch.equal(handoff[1], recomputed[1]) and torch.equal(handoff[2], recomputed[2])
+    if d == 64 and 193 <= n <= 204:     # round 4: this shape's default is the ONE-kernel backward on the bf16 matrix cores (csrc/attention16.hip):
+        for i in (1, 2):                # dK / dV come from other kernels than the recompute path's -- same rounding points, another summation order
+            sc_ = float(exact[i].abs().max())
+            assert float((handoff[i] - recomputed[i]).abs().max()) / sc_ < 1e-2
+            assert 0 < float((handoff[i] - exact[i]).abs().max()) / sc_ < 3e-2
+    else:
+        assert torch.equal(handoff[1], recomputed[1]) and torch.equal(handoff[2], recomputed[2])
     scale = float(exact[0].abs().max())
     e_new = float((handoff[0] - exact[0]).abs().max()) / scale
     e_old = float((recomputed[0] - exact[0]).abs().max()) / scale
