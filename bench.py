@@ -132,7 +132,7 @@ def cpu_baseline(model, wl, target_s=15.0):
                       f"per-sample x per-head loop, after a 1-image warm-up step ({t1:.2f} s)"}
 
 
-PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
+PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
 
 
 def _pmc_traffic(tag, workload, batch):

@@ -685,8 +685,9 @@ __device__ __forceinline__ void attn16_bwd_body(const AttnArgs& a, float* __rest
         float dl = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + 1024 + row * D + 16 * part + 4 * j);
-            const f32x4 o4 = *reinterpret_cast<const f32x4*>(sl + 2048 + row * D + 16 * part + 4 * j);
+            const int jr = (j + row) & 3;       // (rows are 256 bytes apart: without the rotation the four rows of a 16-lane read group share their banks)
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sl + 1024 + row * D + 16 * part + 4 * jr);
+            const f32x4 o4 = *reinterpret_cast<const f32x4*>(sl + 2048 + row * D + 16 * part + 4 * jr);
             dl += d4[0] * o4[0] + d4[1] * o4[1] + d4[2] * o4[2] + d4[3] * o4[3];
         }
         dl += __shfl_xor(dl, 1);
