@@ -177,88 +177,109 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         }
     };
     const int tok_per_blk = BF ? 16 : 2 * UB;
-    const int nblk = (len + tok_per_blk - 1) / tok_per_blk;
+    // wave-uniform by construction, and the compiler must know it: with a per-lane block count the guards below are exec-masked regions,
+    // the refill of a ring slot lands in temporaries that are copied into the slot at the region's end -- behind an s_waitcnt vmcnt(0)
+    // on the loads just issued, i.e. a prefetch distance of zero (found in the ISA, round 4: the bf16 launch ran at the memory latency,
+    // 3 450 cycles per block of 480 MFMA cycles)
+    const int nblk = __builtin_amdgcn_readfirstlane((len + tok_per_blk - 1) / tok_per_blk);
     if constexpr (PG) {
 #pragma unroll
         for (int k = 0; k < TPB; ++k) walk_fill(k);
     }
+    // The ring is filled and refilled UNCONDITIONALLY (rows past the slab are clamped to its last row; their dY is zeroed when the block
+    // leaves the ring) and the loop runs whole groups of PD blocks without a guard; only the last nblk % PD blocks are guarded, and they
+    // refill nothing.  hipcc's s_waitcnt placement is path-insensitive: with a guarded prologue ("if (q < nblk)") there is a path on
+    // which slot 0 holds the YOUNGEST loads, so every block waited for all but the last few loads in flight -- vmcnt(28) .. vmcnt(0)
+    // where vmcnt(63) is meant -- and the prefetch ring was one block deep at best.
 #pragma unroll
-    for (int q = 0; q < PD; ++q)
-        if (q < nblk) {
-            load_block(q, q);
-            if constexpr (PG) {
+    for (int q = 0; q < PD; ++q) {
+        load_block(q, q);
+        if constexpr (PG) {
 #pragma unroll
-                for (int k = 0; k < TPB; ++k) walk_fill(k);
-            }
+            for (int k = 0; k < TPB; ++k) walk_fill(k);
         }
+    }
 
-    for (int blk0 = 0; blk0 < nblk; blk0 += PD) {
+    auto body = [&](auto qc, int blk, auto refill) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        constexpr bool REFILL = decltype(refill)::value;
+        // (scheduling fences: left free, the scheduler hoists the refills of two blocks to the top of the loop and saves the slots it is about
+        // to overwrite by copies -- each copy a wait on loads that should stay in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        // take the block out of the ring (this is where the loads are waited for), zero dY of rows past the slab
+        float cx[NTOK], cu[RBF ? NTOK : 1], cdy[NTOK][NOT];
 #pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            const int blk = blk0 + q;
-            if (blk < nblk) {
-                // take the block out of the ring (this is where the loads are waited for), zero dY of rows past the slab
-                float cx[NTOK], cu[RBF ? NTOK : 1], cdy[NTOK][NOT];
-#pragma unroll
-                for (int t = 0; t < NTOK; ++t) {
-                    const bool ok = tok_of(blk, t) < len;
-                    cx[t] = rx[q][t];
-                    if constexpr (RBF) {
-                        if (ln) {
-                            const int tk = tok_of(blk, t);
-                            const float2 st = st_w[tk < len ? tk : len - 1];
-                            cu[t] = (rx[q][t] - st.x) * st.y * ln_g + ln_b;
-                        } else {
-                            cu[t] = ru[q][t];
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < NOT; ++i) cdy[t][i] = ok ? rdy[q][t][i] : 0.0f;
-                }
-                if (blk + PD < nblk) load_block(q, blk + PD);
-                if constexpr (!BF) {
-#pragma unroll
-                    for (int t = 0; t < NTOK; ++t) {
-                        walk_fill(2 * t);                      // (patch gather) two rows of the next block per MFMA group
-                        walk_fill(2 * t + 1);
-                        BasisGenP<FAM, JC, J0C> gen = proto;
-                        gen.init(cx[t], RBF ? cu[t] : 0.0f);
-#pragma unroll
-                        for (int j = 0; j < JC; ++j) {
-                            const float av = gen.next(j);
-#pragma unroll
-                            for (int i = 0; i < NOT; ++i)
-                                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
-                        }
-                    }
+        for (int t = 0; t < NTOK; ++t) {
+            const bool ok = tok_of(blk, t) < len;
+            cx[t] = rx[q][t];
+            if constexpr (RBF) {
+                if (ln) {
+                    const int tk = tok_of(blk, t);
+                    const float2 st = st_w[tk < len ? tk : len - 1];
+                    cu[t] = (rx[q][t] - st.x) * st.y * ln_g + ln_b;
                 } else {
-                    unsigned af[JC][4];
-#pragma unroll
-                    for (int ep = 0; ep < 4; ++ep) {
-                        BasisGenP<FAM, JC, J0C> g0_ = proto, g1_ = proto;
-                        g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
-                        g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
-#pragma unroll
-                        for (int j = 0; j < JC; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
-                    }
-                    bf16x8_t bfr[NOT];
-#pragma unroll
-                    for (int i = 0; i < NOT; ++i) {
-                        const u32x4 u4 = {kv_pack_bf16(cdy[0][i], cdy[1][i]), kv_pack_bf16(cdy[2][i], cdy[3][i]),
-                                          kv_pack_bf16(cdy[4][i], cdy[5][i]), kv_pack_bf16(cdy[6][i], cdy[7][i])};
-                        bfr[i] = __builtin_bit_cast(bf16x8_t, u4);
-                    }
-#pragma unroll
-                    for (int j = 0; j < JC; ++j) {
-                        const u32x4 a4 = {af[j][0], af[j][1], af[j][2], af[j][3]};
-                        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, a4);
-#pragma unroll
-                        for (int i = 0; i < NOT; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[i], acc[j][i], 0, 0, 0);
-                    }
+                    cu[t] = ru[q][t];
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NOT; ++i) cdy[t][i] = ok ? rdy[q][t][i] : 0.0f;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (REFILL) load_block(q, blk + PD);
+        if constexpr (!BF) {
+#pragma unroll
+            for (int t = 0; t < NTOK; ++t) {
+                if constexpr (REFILL) {
+                    walk_fill(2 * t);                      // (patch gather) two rows of the next block per MFMA group
+                    walk_fill(2 * t + 1);
+                }
+                BasisGenP<FAM, JC, J0C> gen = proto;
+                gen.init(cx[t], RBF ? cu[t] : 0.0f);
+#pragma unroll
+                for (int j = 0; j < JC; ++j) {
+                    const float av = gen.next(j);
+#pragma unroll
+                    for (int i = 0; i < NOT; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
+                }
+            }
+        } else {
+            unsigned af[JC][4];
+#pragma unroll
+            for (int ep = 0; ep < 4; ++ep) {
+                BasisGenP<FAM, JC, J0C> g0_ = proto, g1_ = proto;
+                g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
+                g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
+#pragma unroll
+                for (int j = 0; j < JC; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
+            }
+            bf16x8_t bfr[NOT];
+#pragma unroll
+            for (int i = 0; i < NOT; ++i) {
+                const u32x4 u4 = {kv_pack_bf16(cdy[0][i], cdy[1][i]), kv_pack_bf16(cdy[2][i], cdy[3][i]),
+                                  kv_pack_bf16(cdy[4][i], cdy[5][i]), kv_pack_bf16(cdy[6][i], cdy[7][i])};
+                bfr[i] = __builtin_bit_cast(bf16x8_t, u4);
+            }
+#pragma unroll
+            for (int j = 0; j < JC; ++j) {
+                const u32x4 a4 = {af[j][0], af[j][1], af[j][2], af[j][3]};
+                const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, a4);
+#pragma unroll
+                for (int i = 0; i < NOT; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[i], acc[j][i], 0, 0, 0);
+            }
+        }
+    };
+    int blk0 = 0;
+    for (; blk0 + PD <= nblk; blk0 += PD) {
+        body(std::integral_constant<int, 0>{}, blk0, std::true_type{});
+        body(std::integral_constant<int, 1>{}, blk0 + 1, std::true_type{});
+        if constexpr (PD > 2) body(std::integral_constant<int, 2>{}, blk0 + 2, std::true_type{});
+    }
+    static_assert(PD == 2 || PD == 3, "the group above is written out for two or three ring slots");
+    if (blk0 < nblk) body(std::integral_constant<int, 0>{}, blk0, std::false_type{});
+    if constexpr (PD > 2) {
+        if (blk0 + 1 < nblk) body(std::integral_constant<int, 1>{}, blk0 + 1, std::false_type{});
     }
 
     // dW partial of this slab: row k = (fb*32 + acc row)*GP + j, 32 contiguous columns per row
@@ -620,6 +641,31 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
         p.nt = 1;
         p.nos = p.tiles_per_bg;
     }
+    // ChebyKAN, three column tiles per wave: the LDS-DMA form (kan_bwd_weight_dma.hip) -- every bf16-mode launch, and the exact fp32
+    // launches with more than one group (q|k|v; a one-group fp32 layer keeps the register form, whose sums the patch-gather kernel
+    // reproduces bit for bit).  One work-group per CU (128 KiB of rings), four row ranges each: the slab count is the number of
+    // work-groups per wave unit that fills the CUs r times; taken only when that fills at least 85 % of the last round.
+    if (fam == KANVIT_CHEBY && p.nt == 3 && !kv_config().bw_no_dma && (bf16_mode || d->groups > 1) && d->ldx % 4 == 0 && d->ldy % 4 == 0) {
+        const long long units = (long long)p.nbg * p.nfb * p.nos;
+        long long r = 1;
+        while ((long long)N_CU * r < units) ++r;
+        long long S = (long long)N_CU * r / units;
+        const long long smax = d->M / 256;            // at least 64 rows per wave
+        if (S > smax) S = smax;
+        if (S >= 1 && S <= 65535 && units * S * 100 >= 85LL * N_CU * r) {
+            long long rps = (d->M + S - 1) / S;
+            rps = (rps + 63) / 64 * 64;
+            const long long ld = d->ldx > d->ldy ? d->ldx : d->ldy;
+            if (rps / 4 * ld + ld < (1LL << 29) && units * S < (1LL << 31)) {
+                p.dma = 1;
+                p.rows_per_slab = rps;
+                p.slabs = (int)((d->M + rps - 1) / rps);
+                p.ws_bytes = p.slabs > 1 ? sizeof(float) * (size_t)p.slabs * d->groups * ((size_t)d->I * p.gp) * d->O : 0;
+                p.ok = true;
+                return p;
+            }
+        }
+    }
     // one live wave per SIMD (the accumulator block fills the register file): size the slab count so that the live waves
     // (work-groups whose 2x2 wave grid is only partly populated retire their idle waves at once) cover the chip r times
     const long long units = (long long)p.nbg * p.nfb * p.nos * p.njc;
@@ -652,7 +698,11 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
 // (Measured and removed, round 3: an XCD-aware order of the work-groups -- every XCD one contiguous range of the (slab, unit) order, so
 // that waves sharing a dY tile or an x feature block meet in one L2 -- changed no weight-gradient launch by more than the run-to-run
 // noise (ChebyKAN / B-spline / FastKAN / SineKAN G = 28, fp32 and bf16): these kernels wait on their prefetch depth, not on L2 misses.)
-int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) { return dispatch_bwd_weight_reg(family, a, p, bf, st); }
+int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st) {
+    // (rows of x / dY off the 16-byte grid -- a view into the middle of a tensor: the register form runs the same plan, correct and slower)
+    if (p.dma && kv_bwd_weight_dma_aligned(a)) return kv_bwd_weight_dma(family, a, p, bf, st);
+    return dispatch_bwd_weight_reg(family, a, p, bf, st);
+}
 
 // the plans whose kernels exist in the patch-gather form (dispatch_bwd_weight_reg's HAS_PG instantiations): the patch-embedding
 // layers VisionTransformer builds (model.py:67-80: ChebyKAN degree 4, SineKAN / FourierKAN at grid 28)

@@ -247,6 +247,7 @@ struct BwRegPlan {
     int gp, nt, nfb, nos, tiles_per_bg, nbg, shared, slabs, njc;
     int t16;              // 1: the 16-row-tile kernel (nt = 16-column tiles per wave, nfb = 16-feature blocks)
     int bf;               // 1: the planned kernel contracts on the bf16 matrix cores (KANVIT_FLAG_BF16_MFMA allows it; the exact kernels ignore it)
+    int dma;              // 1: the LDS-DMA form (kan_bwd_weight_dma.hip): a work-group = four row ranges of one wave unit, slabs counts WORK-GROUP slabs
     long long rows_per_slab;
     size_t ws_bytes;
 };
@@ -272,3 +273,5 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d);
 int kv_bwd_weight_reg(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st);
 int kv_slab_reduce(const float* slab, float* dw, long long total, int slabs, hipStream_t st);
 bool kv_bwd_weight_reg_pg_ok(const kanvit_layer_desc* d, const BwRegPlan& p);      // the plan's kernel exists in the patch-gather form
+int kv_bwd_weight_dma(int family, LayerArgs& a, const BwRegPlan& p, bool bf, hipStream_t st);      // kan_bwd_weight_dma.hip
+bool kv_bwd_weight_dma_aligned(const LayerArgs& a);

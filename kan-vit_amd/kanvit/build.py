@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libkanvit.so")
 # the fused KAN layer kernels are one translation unit per kernel generation (kan_layer_common.h): parallel compiles, and a
 # rebuild costs only the kernel that changed
 SOURCES = ["kan_tile.hip", "kan_fwd_reg.hip", "kan_fwd_reg_bf16.hip", "kan_bwd_input_reg.hip", "kan_bwd_input_reg_bf16.hip",
-           "kan_bwd_weight_reg.hip", "kan_layer.hip", "attention.hip", "attention16.hip", "attention_x.hip", "addln.hip", "split3.hip", "ff_small.hip", "ff_epilogue.hip", "kan_tiny.hip"]
+           "kan_bwd_weight_reg.hip", "kan_bwd_weight_dma.hip", "kan_layer.hip", "attention.hip", "attention16.hip", "attention_x.hip", "addln.hip", "split3.hip", "ff_small.hip", "ff_epilogue.hip", "kan_tiny.hip"]
 HEADERS = ["kan_basis.h", "kanvit_common.h", "kan_layer_common.h", "attention_common.h", os.path.join(INCLUDE, "kanvit.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=on", "-fno-finite-math-only", "-fvisibility=hidden"]
 
