@@ -261,6 +261,208 @@ __global__ __launch_bounds__(256, FAM == KV_SINE ? 1 : 2) void kan_bwd_input_reg
     }
 }
 
+// =============================================================================================
+// The same kernel with the dY of its row tile RESIDENT (round 4), for the per-head layers (O = 64, at most three groups sharing x).
+// The kernel above asks for the dY columns of step t + 1 during step t: one step is 20 MFMAs of 32 cycles per wave, the memory latency
+// several times that, and a work-group lives for nci * nshare = 6 .. 12 steps -- it spent its life waiting (q|k|v of ViT-B ChebyKAN:
+// 0.142 ms for 390 MB, 10.7 % matrix-pipe busy).  A row's dY is the same in every feature chunk ci, so it is loaded ONCE, all groups
+// in one burst in the prologue, rounded to bf16 (16 registers per group) and kept: the steps then wait only for W (L2-resident, one
+// step ahead through the LDS double buffer) and for the next chunk's x (a chunk ahead), and the other work-group of the CU covers
+// the prologue.  Same operands, same roundings, same order of the sums as the kernel above: bitwise the same dx.
+// =============================================================================================
+template <int FAM, int GP, int KT, int NSH, bool SHARED>
+__global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const LayerArgs a) {
+    static_assert(FAM != KV_SINE, "SineKAN keeps the streaming kernel (its d freq partials)");
+    static_assert(NSH == 1 || NSH == 3, "one group, or q|k|v");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KCT = 32 * KT;
+    constexpr int FPH = (16 * KT) / GP;
+    constexpr int IC = 2 * FPH;
+    constexpr bool RBF = (FAM == KV_RBF);
+    constexpr int NKS = 4;                        // O = 64 (host-checked)
+    constexpr int WSZ = NKS * 2 * KCT * 8;        // bf16 elements per W buffer
+    constexpr int NV = NKS * 2 * KCT;             // 16-byte vectors per W buffer
+    constexpr int WQ = (NV + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int gx = blockIdx.x;
+    const long long m0 = (long long)blockIdx.y * BM;
+    const int nci = a.I / IC;
+    const int mrem = (m0 + BM <= a.M) ? BM : (int)(a.M - m0);
+    const int row = wave * 32 + l31;
+    const bool row_ok = row < mrem;
+    const long long grow = m0 + (row_ok ? row : 0);
+    unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [2][NKS][2][KCT][8]
+    const float* xrow = a.x + grow * a.ldx + (long long)gx * a.I + hf * FPH;
+    float* dxrow = a.dx + grow * a.ldx + (long long)gx * a.I + hf * FPH;
+    const float* dyrow = a.dy + grow * a.ldy + hf * 8;
+
+    u32x4 wreg[WQ];
+    auto load_w = [&](int ci, int g) __attribute__((always_inline)) {
+        const unsigned short* src = a.wb2 + (((long long)g * nci + ci) * NV) * 8;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int v = tid + q * 256;
+            wreg[q] = *reinterpret_cast<const u32x4*>(src + (long long)(v < NV ? v : 0) * 8);
+        }
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
+        unsigned short* dst = W_s + (size_t)buf * WSZ;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int v = tid + q * 256;
+            if (v < NV) *reinterpret_cast<u32x4*>(dst + (size_t)v * 8) = wreg[q];
+        }
+    };
+    float xv[FPH], xn[FPH];
+    auto load_x = [&](int ci, float (&dst)[FPH]) __attribute__((always_inline)) {
+        if constexpr (FPH % 4 == 0) {
+#pragma unroll
+            for (int j4 = 0; j4 < FPH / 4; ++j4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + ci * IC + 4 * j4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[4 * j4 + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < FPH; ++j) dst[j] = xrow[ci * IC + j];
+        }
+    };
+
+    // ---- prologue: W of step 0, x of chunk 0, and ALL of this row's dY (NSH groups x 64 columns; this lane: its 8 of every 16) ----
+    load_w(0, gx);
+    f32x4 raw[NSH][NKS][2];
+#pragma unroll
+    for (int p = 0; p < NSH; ++p) {
+        const float* src = dyrow + (long long)(p * a.xmod + gx) * a.O;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            raw[p][ks][0] = *reinterpret_cast<const f32x4*>(src + 16 * ks);
+            raw[p][ks][1] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+        }
+    }
+    load_x(0, xn);
+    float2 ln_st = {0.0f, 1.0f};                  // KANVIT_FLAG_FUSED_LN: (mean, rstd) of this lane's row and x slice
+    if constexpr (RBF) {
+        if (a.ln) ln_st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
+    }
+    store_w(0);
+    bf16x8_t dyres[NSH][NKS];
+#pragma unroll
+    for (int p = 0; p < NSH; ++p)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4 u = {kv_pack_bf16(raw[p][ks][0][0], raw[p][ks][0][1]), kv_pack_bf16(raw[p][ks][0][2], raw[p][ks][0][3]),
+                             kv_pack_bf16(raw[p][ks][1][0], raw[p][ks][1][1]), kv_pack_bf16(raw[p][ks][1][2], raw[p][ks][1][3])};
+            dyres[p][ks] = __builtin_bit_cast(bf16x8_t, u);
+        }
+    __syncthreads();
+
+    const int T = nci * NSH;
+    f32x16 acc[KT];
+    float dxacc[FPH];
+    float lnp[RBF ? 2 * FPH : 1];
+    for (int ci = 0; ci < nci; ++ci) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < FPH; ++j) {
+            dxacc[j] = 0.0f;
+            xv[j] = xn[j];
+        }
+        if (ci + 1 < nci) load_x(ci + 1, xn);
+#pragma unroll
+        for (int p = 0; p < NSH; ++p) {
+            const int t = ci * NSH + p;
+            const int g = p * a.xmod + gx;
+            if constexpr (RBF) {                  // the chain rule's gamma / beta (or u): requested before the W prefetch (in-order returns)
+                if (a.ln) {
+                    const float* gb = a.bp + (long long)g * a.bp_stride + a.G + ci * IC + hf * FPH;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) {
+                        lnp[j] = gb[j];
+                        lnp[FPH + j] = gb[a.I + j];
+                    }
+                } else {
+                    const float* urow = a.u ? a.u + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC : xrow + ci * IC;
+#pragma unroll
+                    for (int j = 0; j < FPH; ++j) lnp[j] = urow[j];
+                }
+            }
+            if (t + 1 < T) {
+                const int pn = p + 1 == NSH ? 0 : p + 1, cin = p + 1 == NSH ? ci + 1 : ci;
+                load_w(cin, pn * a.xmod + gx);
+            }
+            const unsigned short* wp = W_s + (size_t)(t & 1) * WSZ + ((size_t)hf * KCT + l31) * 8;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)(2 * ks) * KCT + kt * 32) * 8);
+                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, dyres[p][ks], acc[kt], 0, 0, 0);
+                }
+            if (!SHARED || p == NSH - 1) {
+                const BasisArgs b = make_basis(a, g);
+                float duv[RBF ? FPH : 1];
+                float uvv[RBF ? FPH : 1];
+                if constexpr (RBF) {
+                    if (a.ln) {
+#pragma unroll
+                        for (int j = 0; j < FPH; ++j) uvv[j] = (xv[j] - ln_st.x) * ln_st.y * lnp[j] + lnp[FPH + j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FPH; ++j) uvv[j] = lnp[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FPH; ++j) {
+                    BasisDGen<FAM, kv_gc(FAM, GP)> gen;
+                    gen.init(b, xv[j], RBF ? uvv[j] : 0.0f, ci * IC + hf * FPH + j);
+                    float dsum = 0.0f, usum = 0.0f;
+#pragma unroll
+                    for (int g_ = 0; g_ < GP; ++g_) {
+                        const int slot = j * GP + g_;
+                        const float d = gen.next(g_);
+                        const float v = acc[slot / 16][slot % 16];
+                        if (RBF && g_ < GP - 1) usum += v * d;
+                        else dsum += v * d;
+                    }
+                    dxacc[j] += dsum;
+                    if constexpr (RBF) duv[j] = usum;
+                }
+                if constexpr (RBF) {
+                    if (a.du && row_ok) {
+                        float* durow = a.du + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC;
+#pragma unroll
+                        for (int j = 0; j < FPH; ++j) durow[j] = duv[j];
+                    }
+                }
+                if (p == NSH - 1 && row_ok) {
+                    if constexpr (FPH % 4 == 0) {
+#pragma unroll
+                        for (int j4 = 0; j4 < FPH / 4; ++j4) {
+                            const f32x4 v = {dxacc[4 * j4], dxacc[4 * j4 + 1], dxacc[4 * j4 + 2], dxacc[4 * j4 + 3]};
+                            *reinterpret_cast<f32x4*>(dxrow + ci * IC + 4 * j4) = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FPH; ++j) dxrow[ci * IC + j] = dxacc[j];
+                    }
+                }
+                if (!SHARED && p < NSH - 1) {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
+                }
+            }
+            if (t + 1 < T) store_w((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+}
+
 template <int FAM, int GP, int KT>
 int launch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t st) {
     const long long total = (long long)a.groups * p.nci * (a.O / 16) * 2 * 32 * KT;
@@ -286,6 +488,25 @@ int launch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t
     const int nshare = a.groups / a.xmod;
     const bool shared = kv_shared_basis<FAM>() && kv_share_ok(FAM, a.flags) && nshare > 1;
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
+    if constexpr (FAM != KV_SINE) {
+        if (a.O == 64 && (nshare == 1 || nshare == 3) && !kv_config().bi_no_res) {      // the per-head layers: dY resident (see the kernel)
+            // (three resident groups fit the register file of two work-groups per CU only for the light chain rules: the B-spline / FastKAN
+            //  instantiations spilled 35 - 158 registers and keep the streaming kernel)
+            constexpr bool RES3 = FAM == KV_LINEAR || FAM == KV_CHEBY;
+            if (nshare == 1) {
+                hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 1, false>), grid, dim3(256), p.lds, st, a);
+                KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
+                return 0;
+            }
+            if constexpr (RES3) {
+                if (shared) {
+                    hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, true>), grid, dim3(256), p.lds, st, a);
+                    KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
+                    return 0;
+                }
+            }
+        }
+    }
     if (shared) {
         if constexpr (kv_shared_basis<FAM>()) {
             hipLaunchKernelGGL((kan_bwd_input_reg_bf16_kernel<FAM, GP, KT, true>), grid, dim3(256), p.lds, st, a);
