@@ -266,9 +266,9 @@ __global__ __launch_bounds__(256, FAM == KV_SINE ? 1 : 2) void kan_bwd_input_reg
 // The kernel above asks for the dY columns of step t + 1 during step t: one step is 20 MFMAs of 32 cycles per wave, the memory latency
 // several times that, and a work-group lives for nci * nshare = 6 .. 12 steps -- it spent its life waiting (q|k|v of ViT-B ChebyKAN:
 // 0.142 ms for 390 MB, 10.7 % matrix-pipe busy).  A row's dY is the same in every feature chunk ci, so it is loaded ONCE, all groups
-// in one burst in the prologue, rounded to bf16 (16 registers per group) and kept: the steps then wait only for W (L2-resident, one
-// step ahead through the LDS double buffer) and for the next chunk's x (a chunk ahead), and the other work-group of the CU covers
-// the prologue.  Same operands, same roundings, same order of the sums as the kernel above: bitwise the same dx.
+// in one burst in the prologue, rounded to bf16 (16 registers per group) and kept; W (L2-resident) arrives by LDS-DMA in a ring of
+// three step images, two steps ahead (no staging registers, no ds_write, one barrier per step); the next chunk's x a chunk ahead;
+// the other work-group of the CU covers the prologue.  Same operands, same roundings, same order of the sums as the kernel above: bitwise the same dx.
 // =============================================================================================
 template <int FAM, int GP, int KT, int NSH, bool SHARED>
 __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const LayerArgs a) {
@@ -282,8 +282,9 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     constexpr int NKS = 4;                        // O = 64 (host-checked)
     constexpr int WSZ = NKS * 2 * KCT * 8;        // bf16 elements per W buffer
     constexpr int NV = NKS * 2 * KCT;             // 16-byte vectors per W buffer
-    constexpr int WQ = (NV + 255) / 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+    constexpr int WQ = NV / 256;                  // LDS-DMA instructions per thread and buffer
+    static_assert(NV % 256 == 0, "whole DMA instructions (KT * 256 vectors per buffer)");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hf = lane >> 5;
     const int gx = blockIdx.x;
     const long long m0 = (long long)blockIdx.y * BM;
     const int nci = a.I / IC;
@@ -291,26 +292,24 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     const int row = wave * 32 + l31;
     const bool row_ok = row < mrem;
     const long long grow = m0 + (row_ok ? row : 0);
-    unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [2][NKS][2][KCT][8]
+    unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [3][NKS][2][KCT][8]: a ring of three step images
     const float* xrow = a.x + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     float* dxrow = a.dx + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     const float* dyrow = a.dy + grow * a.ldy + hf * 8;
+    const int T = nci * NSH;
 
-    u32x4 wreg[WQ];
-    auto load_w = [&](int ci, int g) __attribute__((always_inline)) {
-        const unsigned short* src = a.wb2 + (((long long)g * nci + ci) * NV) * 8;
+    // W of step t (feature chunk t / NSH, group t % NSH) -> ring slot t % 3, by LDS-DMA: the packed image is copied as it stands, 16 bytes
+    // per lane and instruction, WQ instructions per thread; no register, no ds_write.  Issued two steps ahead (see the loop).
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto fill_w = [&](int t) __attribute__((always_inline)) {
+        const int ci = t / NSH, g = (t - ci * NSH) * a.xmod + gx;
+        const unsigned short* src = a.wb2 + (((long long)g * nci + ci) * NV) * 8 + (long long)lane * 8;      // this lane's 16 bytes of a 1 KiB piece
+        unsigned short* dst = W_s + (size_t)(t % 3) * WSZ;
 #pragma unroll
         for (int q = 0; q < WQ; ++q) {
-            const int v = tid + q * 256;
-            wreg[q] = *reinterpret_cast<const u32x4*>(src + (long long)(v < NV ? v : 0) * 8);
-        }
-    };
-    auto store_w = [&](int buf) __attribute__((always_inline)) {
-        unsigned short* dst = W_s + (size_t)buf * WSZ;
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const int v = tid + q * 256;
-            if (v < NV) *reinterpret_cast<u32x4*>(dst + (size_t)v * 8) = wreg[q];
+            const int piece = wave + 4 * q;           // uniform: 64 consecutive vectors
+            __builtin_amdgcn_global_load_lds((glb_ptr)(src + (long long)piece * 512), (lds_ptr)(dst + piece * 512), 16, 0, 0);
         }
     };
     float xv[FPH], xn[FPH];
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
         }
     };
 
-    // ---- prologue: W of step 0, x of chunk 0, and ALL of this row's dY (NSH groups x 64 columns; this lane: its 8 of every 16) ----
-    load_w(0, gx);
+    // ---- prologue: ALL of this row's dY (NSH groups x 64 columns; this lane: its 8 of every 16), x of chunk 0, then W of steps 0 and 1 ----
     f32x4 raw[NSH][NKS][2];
 #pragma unroll
     for (int p = 0; p < NSH; ++p) {
@@ -345,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     if constexpr (RBF) {
         if (a.ln) ln_st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
     }
-    store_w(0);
+    fill_w(0);
+    if (T > 1) fill_w(1);
     bf16x8_t dyres[NSH][NKS];
 #pragma unroll
     for (int p = 0; p < NSH; ++p)
@@ -355,9 +354,8 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
                              kv_pack_bf16(raw[p][ks][1][0], raw[p][ks][1][1]), kv_pack_bf16(raw[p][ks][1][2], raw[p][ks][1][3])};
             dyres[p][ks] = __builtin_bit_cast(bf16x8_t, u);
         }
-    __syncthreads();
 
-    const int T = nci * NSH;
+    constexpr int UNR = SHARED ? NSH : 1;
     f32x16 acc[KT];
     float dxacc[FPH];
     float lnp[RBF ? 2 * FPH : 1];
@@ -372,10 +370,26 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
             xv[j] = xn[j];
         }
         if (ci + 1 < nci) load_x(ci + 1, xn);
-#pragma unroll
+        // groups that share the basis (one chain rule per chunk): the group loop is unrolled, dyres[p] a register name; groups that only
+        // share x (a chain rule per group -- three copies of it unrolled spilled 46 - 98 registers): a rolled loop that selects its dY
+#pragma unroll UNR
         for (int p = 0; p < NSH; ++p) {
             const int t = ci * NSH + p;
             const int g = p * a.xmod + gx;
+            bf16x8_t dyb[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if constexpr (SHARED || NSH == 1) {
+                    dyb[ks] = dyres[p < NSH ? p : 0][ks];
+                } else {
+                    const u32x4 v0 = __builtin_bit_cast(u32x4, dyres[0][ks]), v1 = __builtin_bit_cast(u32x4, dyres[NSH > 1 ? 1 : 0][ks]),
+                                v2 = __builtin_bit_cast(u32x4, dyres[NSH > 2 ? 2 : 0][ks]);
+                    u32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = p == 0 ? v0[e] : (p == 1 ? v1[e] : v2[e]);
+                    dyb[ks] = __builtin_bit_cast(bf16x8_t, v);
+                }
+            }
             if constexpr (RBF) {                  // the chain rule's gamma / beta (or u): requested before the W prefetch (in-order returns)
                 if (a.ln) {
                     const float* gb = a.bp + (long long)g * a.bp_stride + a.G + ci * IC + hf * FPH;
@@ -390,17 +404,19 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
                     for (int j = 0; j < FPH; ++j) lnp[j] = urow[j];
                 }
             }
-            if (t + 1 < T) {
-                const int pn = p + 1 == NSH ? 0 : p + 1, cin = p + 1 == NSH ? ci + 1 : ci;
-                load_w(cin, pn * a.xmod + gx);
-            }
-            const unsigned short* wp = W_s + (size_t)(t & 1) * WSZ + ((size_t)hf * KCT + l31) * 8;
+            // W of this step has landed for this thread (one younger image may still be in flight), then for the work-group; behind the
+            // barrier every wave has also left step t - 1, whose ring slot takes the image of step t + 2.  One barrier per step.
+            if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 2 < T) fill_w(t + 2);
+            const unsigned short* wp = W_s + (size_t)(t % 3) * WSZ + ((size_t)hf * KCT + l31) * 8;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(wp + ((size_t)(2 * ks) * KCT + kt * 32) * 8);
-                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, dyres[p][ks], acc[kt], 0, 0, 0);
+                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, dyb[ks], acc[kt], 0, 0, 0);
                 }
             if (!SHARED || p == NSH - 1) {
                 const BasisArgs b = make_basis(a, g);
@@ -457,8 +473,6 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
                         for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
                 }
             }
-            if (t + 1 < T) store_w((t + 1) & 1);
-            __syncthreads();
         }
     }
 }
@@ -490,20 +504,22 @@ int launch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
     if constexpr (FAM != KV_SINE) {
         if (a.O == 64 && (nshare == 1 || nshare == 3) && !kv_config().bi_no_res) {      // the per-head layers: dY resident (see the kernel)
-            // (three resident groups fit the register file of two work-groups per CU only for the light chain rules: the B-spline / FastKAN
-            //  instantiations spilled 35 - 158 registers and keep the streaming kernel)
-            constexpr bool RES3 = FAM == KV_LINEAR || FAM == KV_CHEBY;
+            const size_t lds3 = (size_t)3 * 4 * 2 * 32 * KT * 16;      // a ring of three W step images
             if (nshare == 1) {
-                hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 1, false>), grid, dim3(256), p.lds, st, a);
+                hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 1, false>), grid, dim3(256), lds3, st, a);
                 KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
                 return 0;
             }
-            if constexpr (RES3) {
-                if (shared) {
-                    hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, true>), grid, dim3(256), p.lds, st, a);
+            if (shared) {
+                if constexpr (kv_shared_basis<FAM>()) {
+                    hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, true>), grid, dim3(256), lds3, st, a);
                     KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
                     return 0;
                 }
+            } else {
+                hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, false>), grid, dim3(256), lds3, st, a);
+                KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
+                return 0;
             }
         }
     }

@@ -22,8 +22,14 @@ namespace {
 typedef const __attribute__((address_space(1))) void* kvd_glb_ptr;
 typedef __attribute__((address_space(3))) void* kvd_lds_ptr;
 
-constexpr int KVD_NSLOT = 4;      // ring slots per wave
+#ifndef KVD_NSLOT_N
+#define KVD_NSLOT_N 4
+#endif
+constexpr int KVD_NSLOT = KVD_NSLOT_N;      // ring slots per wave
 constexpr int KVD_BLK = 16;       // rows per block
+#ifndef KVD_ABLATE
+#define KVD_ABLATE 0      // diagnostic builds (tools/build_variant.sh): 1 = no contraction (fills and waits only), 2 = no fills
+#endif
 
 template <int N>
 __device__ __forceinline__ void kvd_wait_vm() {
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_dma_kernel(const LayerArgs
     // one block into one slot.  The last block of a row range that is not a multiple of 16 re-reads its last row for the missing ones
     // (the consumer zeroes their dY): a uniform branch, the offsets of every other block are the ones formed above.
     auto issue = [&](int blk, int slot) __attribute__((always_inline)) {
+        if (KVD_ABLATE & 2) return;
         float* dst = ring + slot * SLOTF;
         const bool ragged = (blk + 1) * KVD_BLK > len;
         if (!ragged) {
@@ -172,6 +179,8 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_dma_kernel(const LayerArgs
         const int behind = nblk - 1 - blk;           // uniform
         if (behind >= KVD_NSLOT - 1) {
             issue(blk + KVD_NSLOT - 1, (S + KVD_NSLOT - 1) % KVD_NSLOT);
+            kvd_wait_vm<NDMA * (KVD_NSLOT - 1)>();
+        } else if (KVD_NSLOT > 4 && behind == 3) {
             kvd_wait_vm<NDMA * 3>();
         } else if (behind == 2) {
             kvd_wait_vm<NDMA * 2>();
@@ -180,6 +189,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_dma_kernel(const LayerArgs
         } else {
             kvd_wait_vm<0>();
         }
+        if (KVD_ABLATE & 1) return;
         float cx[8], cdy[8][NOT];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -242,7 +252,11 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_dma_kernel(const LayerArgs
         if (blk0 + 1 < nblk) step(blk0 + 1, std::integral_constant<int, 1>{});
         if (blk0 + 2 < nblk) step(blk0 + 2, std::integral_constant<int, 2>{});
         if (blk0 + 3 < nblk) step(blk0 + 3, std::integral_constant<int, 3>{});
+        if constexpr (KVD_NSLOT > 4) {
+            if (blk0 + 4 < nblk) step(blk0 + 4, std::integral_constant<int, 4>{});
+        }
     }
+    static_assert(KVD_NSLOT == 4 || KVD_NSLOT == 5, "the step sequence above is written out for four or five slots");
 
     // ---- the four partial sums of the work-group, through the LDS: images [accumulator register][lane], two at a time ----
     constexpr int NREG = GP * NOT * 16;
