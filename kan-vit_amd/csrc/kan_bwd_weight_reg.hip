@@ -3,6 +3,14 @@
 
 namespace {
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void kv_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        kv_static_for<N, I + 1>(f);
+    }
+}
+
 // =============================================================================================
 // backward w.r.t. the weights, register form: a barrier-free, LDS-free streaming kernel.
 //   dW[g][i*GP + j][o] = sum_m Phi_j(x[m][i]) * dY[m][g*O + o]
@@ -416,43 +424,48 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_weight_reg16_kernel(const Laye
             }
         };
         const int nblk = (len + 4 * UB - 1) / (4 * UB);
-#pragma unroll
-        for (int q = 0; q < PD; ++q)
-            if (q < nblk) load_block(q, q);
         // A block is copied out of the ring and its slot refilled BEFORE its MFMAs (prefetch distance PD blocks).  Reading the ring
         // registers directly and refilling after the MFMAs saves NC + 1 moves per step but shortens the distance to PD - 1 blocks:
         // measured slower (767 -> 812 us on the ViT-B q|k|v launch) -- at two waves per SIMD this kernel lives on its prefetch depth.
-        for (int blk0 = 0; blk0 < nblk; blk0 += PD) {
+        // The ring is filled and refilled UNCONDITIONALLY (rows past the slab are clamped to its last row) and the loop runs whole
+        // groups of PD blocks without a guard -- as kan_bwd_weight_reg_kernel, and for the same reason: with guards, hipcc's
+        // path-insensitive s_waitcnt placement waited for every load in flight (vmcnt(12), vmcnt(0) per block) instead of the oldest block.
 #pragma unroll
-            for (int q = 0; q < PD; ++q) {
-                const int blk = blk0 + q;
-                if (blk < nblk) {
-                    float cx[UB], cu[UB], cdy[UB][NC];
-                    bool ok[UB];
+        for (int q = 0; q < PD; ++q) load_block(q, q);
+        auto body = [&](auto qc, int blk, auto refill) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            constexpr bool REFILL = decltype(refill)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            float cx[UB], cu[UB], cdy[UB][NC];
+            bool ok[UB];
 #pragma unroll
-                    for (int t = 0; t < UB; ++t) {
-                        ok[t] = tok_of(blk, t) < len;
-                        cx[t] = rx[q][t];
-                        cu[t] = 0.0f;
-                        if constexpr (RBF) cu[t] = ln ? (rx[q][t] - ru[q][t].x) * ru[q][t].y * ln_g + ln_b : ru[q][t].x;
+            for (int t = 0; t < UB; ++t) {
+                ok[t] = tok_of(blk, t) < len;
+                cx[t] = rx[q][t];
+                cu[t] = 0.0f;
+                if constexpr (RBF) cu[t] = ln ? (rx[q][t] - ru[q][t].x) * ru[q][t].y * ln_g + ln_b : ru[q][t].x;
 #pragma unroll
-                        for (int i = 0; i < NC; ++i) cdy[t][i] = rdy[q][t][i];
-                    }
-                    if (blk + PD < nblk) load_block(q, blk + PD);
+                for (int i = 0; i < NC; ++i) cdy[t][i] = rdy[q][t][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (REFILL) load_block(q, blk + PD);
 #pragma unroll
-                    for (int t = 0; t < UB; ++t) {
-                        BasisGenP<FAM, JC, J0C> gen = proto;
-                        gen.init(cx[t], cu[t]);
+            for (int t = 0; t < UB; ++t) {
+                BasisGenP<FAM, JC, J0C> gen = proto;
+                gen.init(cx[t], cu[t]);
 #pragma unroll
-                        for (int j = 0; j < JC; ++j) {
-                            const float av = ok[t] ? gen.next(j) : 0.0f;          // rows past the slab contribute nothing (JC selects, not NC)
+                for (int j = 0; j < JC; ++j) {
+                    const float av = ok[t] ? gen.next(j) : 0.0f;          // rows past the slab contribute nothing (JC selects, not NC)
 #pragma unroll
-                            for (int i = 0; i < NC; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
-                        }
-                    }
+                    for (int i = 0; i < NC; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
                 }
             }
-        }
+        };
+        int blk0 = 0;
+        for (; blk0 + PD <= nblk; blk0 += PD) kv_static_for<PD>([&](auto qc) __attribute__((always_inline)) { body(qc, blk0 + decltype(qc)::value, std::true_type{}); });
+        kv_static_for<PD - 1>([&](auto qc) __attribute__((always_inline)) {
+            if (blk0 + decltype(qc)::value < nblk) body(qc, blk0 + decltype(qc)::value, std::false_type{});
+        });
         // dW partial of this slab: row k = (fb*16 + 4*tq + r)*GP + J0C + j, 16 contiguous columns per row and tile
         float* base = a.slab + (long long)slab * ((long long)a.groups * a.K * a.O);
 #pragma unroll
