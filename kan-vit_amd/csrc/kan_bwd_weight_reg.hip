@@ -189,31 +189,111 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     // the refill of a ring slot lands in temporaries that are copied into the slot at the region's end -- behind an s_waitcnt vmcnt(0)
     // on the loads just issued, i.e. a prefetch distance of zero (found in the ISA, round 4: the bf16 launch ran at the memory latency,
     // 3 450 cycles per block of 480 MFMA cycles)
-    const int nblk = __builtin_amdgcn_readfirstlane((len + tok_per_blk - 1) / tok_per_blk);
+    const int nblk_v = (len + tok_per_blk - 1) / tok_per_blk;
+    const int nblk = PG ? nblk_v : __builtin_amdgcn_readfirstlane(nblk_v);      // (the patch-gather instantiations are scalar already; left exactly as they were: below)
     if constexpr (PG) {
 #pragma unroll
         for (int k = 0; k < TPB; ++k) walk_fill(k);
     }
+    if constexpr (PG) {
+    // The patch-gather form keeps the guarded ring of round 3 as it stood: its control flow is scalar throughout (SCALAR_WAVE), its row
+    // walker is interleaved with the MFMA groups, and every variant of the unguarded ring measured 5 - 8 % SLOWER on its launches
+    // (SineKAN G = 28: 8.40 -> 8.8 - 9.1 ms per pass, with and without the scheduling fences).
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+        if (q < nblk) {
+            load_block(q, q);
+            if constexpr (PG) {
+#pragma unroll
+                for (int k = 0; k < TPB; ++k) walk_fill(k);
+            }
+        }
+
+    for (int blk0 = 0; blk0 < nblk; blk0 += PD) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            const int blk = blk0 + q;
+            if (blk < nblk) {
+                // take the block out of the ring (this is where the loads are waited for), zero dY of rows past the slab
+                float cx[NTOK], cu[RBF ? NTOK : 1], cdy[NTOK][NOT];
+#pragma unroll
+                for (int t = 0; t < NTOK; ++t) {
+                    const bool ok = tok_of(blk, t) < len;
+                    cx[t] = rx[q][t];
+                    if constexpr (RBF) {
+                        if (ln) {
+                            const int tk = tok_of(blk, t);
+                            const float2 st = st_w[tk < len ? tk : len - 1];
+                            cu[t] = (rx[q][t] - st.x) * st.y * ln_g + ln_b;
+                        } else {
+                            cu[t] = ru[q][t];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NOT; ++i) cdy[t][i] = ok ? rdy[q][t][i] : 0.0f;
+                }
+                if (blk + PD < nblk) load_block(q, blk + PD);
+                if constexpr (!BF) {
+#pragma unroll
+                    for (int t = 0; t < NTOK; ++t) {
+                        walk_fill(2 * t);                      // (patch gather) two rows of the next block per MFMA group
+                        walk_fill(2 * t + 1);
+                        BasisGenP<FAM, JC, J0C> gen = proto;
+                        gen.init(cx[t], RBF ? cu[t] : 0.0f);
+#pragma unroll
+                        for (int j = 0; j < JC; ++j) {
+                            const float av = gen.next(j);
+#pragma unroll
+                            for (int i = 0; i < NOT; ++i)
+                                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cdy[t][i], acc[j][i], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    unsigned af[JC][4];
+#pragma unroll
+                    for (int ep = 0; ep < 4; ++ep) {
+                        BasisGenP<FAM, JC, J0C> g0_ = proto, g1_ = proto;
+                        g0_.init(cx[2 * ep], RBF ? cu[2 * ep] : 0.0f);
+                        g1_.init(cx[2 * ep + 1], RBF ? cu[2 * ep + 1] : 0.0f);
+#pragma unroll
+                        for (int j = 0; j < JC; ++j) af[j][ep] = kv_pack_bf16(g0_.next(j), g1_.next(j));
+                    }
+                    bf16x8_t bfr[NOT];
+#pragma unroll
+                    for (int i = 0; i < NOT; ++i) {
+                        const u32x4 u4 = {kv_pack_bf16(cdy[0][i], cdy[1][i]), kv_pack_bf16(cdy[2][i], cdy[3][i]),
+                                          kv_pack_bf16(cdy[4][i], cdy[5][i]), kv_pack_bf16(cdy[6][i], cdy[7][i])};
+                        bfr[i] = __builtin_bit_cast(bf16x8_t, u4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < JC; ++j) {
+                        const u32x4 a4 = {af[j][0], af[j][1], af[j][2], af[j][3]};
+                        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, a4);
+#pragma unroll
+                        for (int i = 0; i < NOT; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[i], acc[j][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    } else {
     // The ring is filled and refilled UNCONDITIONALLY (rows past the slab are clamped to its last row; their dY is zeroed when the block
     // leaves the ring) and the loop runs whole groups of PD blocks without a guard; only the last nblk % PD blocks are guarded, and they
     // refill nothing.  hipcc's s_waitcnt placement is path-insensitive: with a guarded prologue ("if (q < nblk)") there is a path on
     // which slot 0 holds the YOUNGEST loads, so every block waited for all but the last few loads in flight -- vmcnt(28) .. vmcnt(0)
     // where vmcnt(63) is meant -- and the prefetch ring was one block deep at best.
 #pragma unroll
-    for (int q = 0; q < PD; ++q) {
-        load_block(q, q);
-        if constexpr (PG) {
-#pragma unroll
-            for (int k = 0; k < TPB; ++k) walk_fill(k);
-        }
-    }
+    for (int q = 0; q < PD; ++q) load_block(q, q);
 
     auto body = [&](auto qc, int blk, auto refill) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value;
         constexpr bool REFILL = decltype(refill)::value;
+        constexpr bool FENCE = true;
         // (scheduling fences: left free, the scheduler hoists the refills of two blocks to the top of the loop and saves the slots it is about
         // to overwrite by copies -- each copy a wait on loads that should stay in flight)
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
         // take the block out of the ring (this is where the loads are waited for), zero dY of rows past the slab
         float cx[NTOK], cu[RBF ? NTOK : 1], cdy[NTOK][NOT];
 #pragma unroll
@@ -232,15 +312,11 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
 #pragma unroll
             for (int i = 0; i < NOT; ++i) cdy[t][i] = ok ? rdy[q][t][i] : 0.0f;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
         if constexpr (REFILL) load_block(q, blk + PD);
         if constexpr (!BF) {
 #pragma unroll
             for (int t = 0; t < NTOK; ++t) {
-                if constexpr (REFILL) {
-                    walk_fill(2 * t);                      // (patch gather) two rows of the next block per MFMA group
-                    walk_fill(2 * t + 1);
-                }
                 BasisGenP<FAM, JC, J0C> gen = proto;
                 gen.init(cx[t], RBF ? cu[t] : 0.0f);
 #pragma unroll
@@ -290,6 +366,7 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
         if (blk0 + 1 < nblk) body(std::integral_constant<int, 1>{}, blk0 + 1, std::false_type{});
     }
 
+    }
     // dW partial of this slab: row k = (fb*32 + acc row)*GP + j, 32 contiguous columns per row
     float* base = a.slab + (long long)slab * ((long long)a.groups * a.K * a.O);
 #pragma unroll
