@@ -13,6 +13,8 @@
 //   * a work-group is FOUR row ranges of ONE wave unit: the four partial sums are added through the LDS (the ring is dead by then)
 //     in a fixed order, (s0 + s1) + (s2 + s3), so a launch writes a quarter of the slab partials the register form wrote
 //     (q|k|v at ViT-B: 21 slabs -> 5; 124 MB of slab traffic -> 30) and the ordered reduce has a quarter of the work.
+// (Measured and not kept: the two-window B-spline schedule of the bf16 mode in this form -- 257 against 259 us on the ViT-B q|k|v launch: that
+//  kernel is bound by the evaluation of the spline pieces, not by addresses or the ring.)
 // fp32: v_mfma_f32_32x32x2_f32, 8 steps per block; bf16 flag: v_mfma_f32_32x32x16_bf16, one MFMA per (value, tile) and block.
 // grid = 8 XCDs x cap slots (>= units * slabs work-groups, see the mapping in the kernel), 256 threads, 128 KiB LDS.
 #include "kan_layer_common.h"
