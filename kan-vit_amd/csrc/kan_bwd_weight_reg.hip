@@ -740,9 +740,10 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
         long long r = 1;
         while ((long long)N_CU * r < units) ++r;
         long long S = (long long)N_CU * r / units;
-        const long long smax = d->M / 256;            // at least 64 rows per wave
+        const bool force = kv_config().bw_dma_force != 0;        // (parity tests: small shapes through this kernel, down to 16 rows per wave)
+        const long long smax = force ? (d->M / 64 > 0 ? d->M / 64 : 1) : d->M / 256;            // at least 64 rows per wave
         if (S > smax) S = smax;
-        if (S >= 1 && S <= 65535 && units * S * 100 >= 85LL * N_CU * r) {
+        if (S >= 1 && S <= 65535 && (force || units * S * 100 >= 85LL * N_CU * r)) {
             long long rps = (d->M + S - 1) / S;
             rps = (rps + 63) / 64 * 64;
             const long long ld = d->ldx > d->ldy ? d->ldx : d->ldy;

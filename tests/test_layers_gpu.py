@@ -305,6 +305,85 @@ def test_weight_gradient_kernels_agree_and_are_deterministic(fam, amp, monkeypat
     assert float((reg[0] - tile[0]).abs().max()) / float(tile[0].abs().max()) < tol
 
 
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("rows", [4 * 197 + 5, 64, 2049, 3 * 1024])
+def test_chebykan_weight_gradient_lds_dma_form(rows, amp, monkeypatch):
+    """The LDS-DMA form of ChebyKAN's weight gradient (csrc/kan_bwd_weight_dma.hip: wave-private rings filled by global_load_lds,
+    four row ranges per work-group summed through the LDS) against the register-ring form on the same launch: same operands and
+    roundings, fp32 sums in another order.  KANVIT_BW_DMA_FORCE takes shapes that would not fill the chip through it: row ranges
+    that end inside a 16-row block, waves without rows, a single block per wave.  Bitwise reproducible; an x whose rows do not
+    start on 16-byte boundaries falls back to the register form under the same plan."""
+    from attention import MSA
+    from kanvit import _lib, grouped
+    torch.manual_seed(9)
+    msa = MSA(256, 4, type="cheby").to(DEV)
+    xfull = torch.randn(rows, 257, device=DEV)
+    w = torch.randn(rows, 768, device=DEV)
+
+    def grads(x):
+        msa.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+        (y * w).sum().backward()
+        return torch.cat([p.grad.flatten() for p in msa.parameters() if p.grad is not None]).clone()
+
+    x = xfull[:, :256].contiguous()
+    x_off = xfull[:, 1:]                           # rows start 4 bytes off the 16-byte grid (and ldx = 257)
+    monkeypatch.setenv("KANVIT_BW_DMA_FORCE", "1")
+    _lib.reload_config()
+    try:
+        assert "bw_dma_force=1" in _lib.active_config()
+        dma = [grads(x) for _ in range(3)]
+        off = grads(x_off)
+        monkeypatch.setenv("KANVIT_BW_NO_DMA", "1")
+        _lib.reload_config()
+        ring = grads(x)
+        ring_off = grads(x_off)
+    finally:
+        monkeypatch.delenv("KANVIT_BW_DMA_FORCE", raising=False)
+        monkeypatch.delenv("KANVIT_BW_NO_DMA", raising=False)
+        _lib.reload_config()
+    assert all(torch.equal(dma[0], d) for d in dma[1:])
+    scale = float(ring.abs().max())
+    assert torch.isfinite(dma[0]).all() and float((dma[0] - ring).abs().max()) / scale < 1e-5
+    if rows >= 256:
+        assert not torch.equal(dma[0], ring)       # another order of the fp32 sums: the LDS-DMA kernel really ran (below 256 rows neither form applies)
+    assert float((off - ring_off).abs().max()) / float(ring_off.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("fam", ["vanilla", "cheby", "efficientkan", "fast"])
+@pytest.mark.parametrize("rows", [4 * 197 + 5, 128, 1])
+def test_bf16_input_gradient_resident_form_is_bitwise_the_streaming_form(fam, rows, monkeypatch):
+    """The dY-resident bf16 input gradient (a row tile's dY loaded once, W through an LDS-DMA ring of three step images) forms the same
+    products in the same order as the streaming kernel it replaces on the per-head layers: dx (and FastKAN's du path) bit for bit."""
+    from attention import MSA
+    from kanvit import _lib, grouped
+    torch.manual_seed(12)
+    msa = MSA(256, 4, type=fam).to(DEV)
+    x = torch.randn(rows, 256, device=DEV, requires_grad=True)
+    w = torch.randn(rows, 768, device=DEV)
+
+    def dx():
+        msa.zero_grad()
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = grouped.run_qkv(msa.q_mappings, msa.k_mappings, msa.v_mappings, x)
+        (y * w).sum().backward()
+        return x.grad.clone()
+
+    res = [dx(), dx()]
+    monkeypatch.setenv("KANVIT_BI_NO_RES", "1")
+    _lib.reload_config()
+    try:
+        assert "bi_no_res=1" in _lib.active_config()
+        stream = dx()
+    finally:
+        monkeypatch.delenv("KANVIT_BI_NO_RES")
+        _lib.reload_config()
+    assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1])
+    assert torch.equal(res[0], stream), (fam, float((res[0] - stream).abs().max()))
+
+
 def test_bspline_non_uniform_or_differing_grids_take_the_general_path():
     """The closed-form / shared-basis shortcuts are only taken when the knot buffers allow it."""
     from attention import MSA
