@@ -304,7 +304,11 @@ __global__ __launch_bounds__(256) void kan_fwd_reg_bf16_kernel(const LayerArgs a
 //   * x of the next (tile, chunk) is prefetched while the current chunk is contracted; 8 waves (2 per SIMD) of 32 rows.
 // =============================================================================================
 constexpr int KV_WS_THREADS = 512;   // 8 waves (12 measured slower: 66 row tiles over 21 work-groups per head quantise to 79 %)
-template <int FAM, int GP, int NT, int NSH, int ICH, int NCH>
+//   * (round 4) the stores: an accumulator quad is 16 bytes of the lane's own row, so a store instruction used to touch 32 rows with
+//     32 bytes each -- four instructions, 128 write transactions per 128-byte line set; without its stores the ViT-B q|k|v launch
+//     ran in 59 instead of 100 us.  With ST a tile passes through a wave-private LDS strip ([32 rows][36 floats]: b128 writes and
+//     reads conflict free) and leaves as four instructions of eight whole 128-byte lines each.
+template <int FAM, int GP, int NT, int NSH, int ICH, int NCH, bool ST = false>
 __global__ __launch_bounds__(KV_WS_THREADS, KV_WS_THREADS / 256) void kan_fwd_ws_bf16_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 32 * NT;
@@ -323,6 +327,8 @@ __global__ __launch_bounds__(KV_WS_THREADS, KV_WS_THREADS / 256) void kan_fwd_ws
     const int nsets = a.groups / NSH;
     unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [NK][2][WROW][8]
     float* bias_s = reinterpret_cast<float*>(W_s + (size_t)NK * 2 * WROW * 8);   // [WROW] (zeros without a bias)
+    constexpr int STW = 36;                       // row stride of the store strip (floats)
+    float* strip = bias_s + WROW + (ST ? wave * (32 * STW) : 0);      // ST: [32 rows][STW] of this wave
 
     // ---- stage the whole weight image (and the bias of this column set) once
     {
@@ -435,7 +441,32 @@ __global__ __launch_bounds__(KV_WS_THREADS, KV_WS_THREADS / 256) void kan_fwd_ws
                 __builtin_amdgcn_sched_barrier(0);            // keep the one-step-ahead fragment prefetch, no further hoisting
             }
             // accumulator registers 4q..4q+3 of a tile are y[row][.. + 8q + 4hf + 0..3] of this lane's row
-            if (st_ok) {
+            if constexpr (ST) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = t0 + tt;
+                    if (t < NTT) {
+                        const int p = t / NT, nt = t - p * NT;
+                        const int g = (NSH == 1) ? gs : p * nsets + gs;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<f32x4*>(strip + l31 * STW + 8 * q + 4 * hf) =
+                                tt == 0 ? f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]}
+                                        : f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+                        const int pc = lane & 7;                           // 16-byte piece of the 128-byte row segment
+                        f32x4 bv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        if (has_bias) bv = *reinterpret_cast<const f32x4*>(bias_s + t * 32 + 4 * pc);
+                        const long long r0 = tile * ROWS + wave * 32 + (lane >> 3);
+                        float* yp = a.y + r0 * a.ldy + (long long)g * a.O + n0 + nt * 32 + 4 * pc;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            f32x4 v = *reinterpret_cast<const f32x4*>(strip + (8 * k + (lane >> 3)) * STW + 4 * pc);
+                            v += bv;
+                            if (FULL || r0 + 8 * k < a.M) *reinterpret_cast<f32x4*>(yp + (long long)(8 * k) * a.ldy) = v;
+                        }
+                    }
+                }
+            } else if (st_ok) {
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const int t = t0 + tt;
@@ -470,12 +501,18 @@ int launch_fwd_reg_bf16(const LayerArgs& a, const FwdRegBf16Plan& p, hipStream_t
         const size_t wlds = (size_t)p.nch * p.vs * 2 * 32 * NT * NSH * 16 + sizeof(float) * 32 * NT * NSH;
         const int gx = (a.groups / NSH) * (a.O / (32 * NT));
         if (wlds <= 150 * 1024 && p.nch == 4 && a.M >= 4096 && gx <= N_CU && !((uintptr_t)a.y & 15) && !kv_config().no_ws && !a.pg) {
-            KV_ALLOW_LDS(160 * 1024, (kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>));
             const long long ntiles = (a.M + KV_WS_THREADS / 2 - 1) / (KV_WS_THREADS / 2);
             long long py = N_CU / gx;             // one work-group per CU (the image fills the LDS)
             if (py > ntiles) py = ntiles;
             if (py < 1) py = 1;
-            hipLaunchKernelGGL((kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>), dim3((unsigned)gx, (unsigned)py, 1), dim3(KV_WS_THREADS), wlds, st, a);
+            const size_t slds = wlds + sizeof(float) * (KV_WS_THREADS / 64) * 32 * 36;       // + the store strips (see the kernel), when they fit
+            if (slds <= 160 * 1024 && !kv_config().ws_no_strip) {
+                KV_ALLOW_LDS(160 * 1024, (kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4, true>));
+                hipLaunchKernelGGL((kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4, true>), dim3((unsigned)gx, (unsigned)py, 1), dim3(KV_WS_THREADS), slds, st, a);
+            } else {
+                KV_ALLOW_LDS(160 * 1024, (kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>));
+                hipLaunchKernelGGL((kan_fwd_ws_bf16_kernel<FAM, GP, NT, NSH, ICH, 4>), dim3((unsigned)gx, (unsigned)py, 1), dim3(KV_WS_THREADS), wlds, st, a);
+            }
             KV_LAUNCH_CHECK("kan_fwd_ws_bf16_kernel");
             return 0;
         }

@@ -126,6 +126,7 @@ static void kv_config_load() {
     c.bw_no_dma = flag("KANVIT_BW_NO_DMA");
     c.bi_no_res = flag("KANVIT_BI_NO_RES");
     c.bw_dma_force = flag("KANVIT_BW_DMA_FORCE");
+    c.ws_no_strip = flag("KANVIT_WS_NO_STRIP");
     c.no_fast = flag("KANVIT_NO_FAST");
     c.no_pipe = flag("KANVIT_NO_PIPE");
     c.no_ws = flag("KANVIT_NO_WS");
@@ -144,8 +145,8 @@ static void kv_config_load() {
     c.bs_bw_bf16 = num("KANVIT_BSPLINE_BW_BF16");
     c.tail = getenv("KANVIT_TAIL") ? atoi(getenv("KANVIT_TAIL")) : -1;
     snprintf(c.text, sizeof(c.text),
-             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_v4=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d bs_bw_bf16=%d tail=%d bw_no_dma=%d bi_no_res=%d bw_dma_force=%d",
-             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_v4, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid, c.bs_bw_bf16, c.tail, c.bw_no_dma, c.bi_no_res, c.bw_dma_force);
+             "no_reg=%d no_reg_bw=%d bw_no_t16=%d no_fast=%d no_pipe=%d no_ws=%d no_bf16=%d no_fused_ln=%d no_tiny=%d attn_v1=%d attn_v2=%d attn_v3=%d attn_v4=%d attn_no_ds=%d attn_grid=%d bf16_nsh=%d bf16_ic=%d ff_grid=%d bs_bw_bf16=%d tail=%d bw_no_dma=%d bi_no_res=%d bw_dma_force=%d ws_no_strip=%d",
+             c.no_reg, c.no_reg_bw, c.bw_no_t16, c.no_fast, c.no_pipe, c.no_ws, c.no_bf16, c.no_fused_ln, c.no_tiny, c.attn_v1, c.attn_v2, c.attn_v3, c.attn_v4, c.attn_no_ds, c.attn_grid, c.bf16_nsh, c.bf16_ic, c.ff_grid, c.bs_bw_bf16, c.tail, c.bw_no_dma, c.bi_no_res, c.bw_dma_force, c.ws_no_strip);
     g_kv_config = c;
     __atomic_store_n(&g_kv_config_state, 1, __ATOMIC_RELEASE);
 }

@@ -59,9 +59,10 @@ struct KvConfig {
     int bs_bw_bf16;      // KANVIT_BSPLINE_BW_BF16 B-spline weight gradient in bf16 mode: 0 = default (32-row bf16 register kernel), 1 = LDS-tile bf16 kernel, 2 = exact 16-row kernel (A/B)
     int bw_no_dma;       // KANVIT_BW_NO_DMA       ChebyKAN weight gradient in the register-ring form of rounds 1-3 instead of the LDS-DMA form (A/B)
     int bw_dma_force;    // KANVIT_BW_DMA_FORCE    the LDS-DMA weight gradient also where its launch would not fill the chip (small shapes: the parity tests)
+    int ws_no_strip;     // KANVIT_WS_NO_STRIP     W-stationary bf16 forward stores straight from the accumulators (rounds 1-3) instead of through the LDS strips (A/B)
     int bi_no_res;       // KANVIT_BI_NO_RES       bf16 input gradient of the per-head layers in the streaming form of rounds 2-3 instead of the dY-resident form (A/B)
     int tail;            // KANVIT_TAIL            row tiles of a q|k|v launch that run as sub-divided work-groups at the end of the grid: -1 = automatic (default), 0 = off, k = k tiles (tuning)
-    char text[512];
+    char text[544];
 };
 const KvConfig& kv_config();
 
