@@ -293,6 +293,26 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     const bool row_ok = row < mrem;
     const long long grow = m0 + (row_ok ? row : 0);
     unsigned short* W_s = reinterpret_cast<unsigned short*>(smem);     // [3][NKS][2][KCT][8]: a ring of three step images
+    // dx / du leave through a wave-private LDS strip [32 rows][IC + 4] as whole row segments (IC floats per row: a 128-byte line for
+    // ChebyKAN) -- straight from the registers a store instruction touches 32 rows with two 16-byte pieces each (see kan_fwd_ws_bf16_kernel)
+    constexpr int STW = IC + 4, PPR = IC / 4, RPI = 64 / PPR;
+    static_assert(FPH % 4 == 0 && 64 % PPR == 0 && 32 % RPI == 0, "whole 16-byte pieces, whole rows per store instruction");
+    float* strip = reinterpret_cast<float*>(W_s + (size_t)3 * WSZ) + wave * (32 * STW);
+    // (three groups that share only x run a chain rule per group in a rolled loop at the register limit: with the strip code that instantiation
+    //  spilled 59 registers and FastKAN's launch went 301 -> 419 us; it keeps the direct stores)
+    constexpr bool STRIP = SHARED || NSH == 1;
+    auto store_tile = [&](const float (&v)[FPH], float* dst, long long ld) __attribute__((always_inline)) {      // dst: (row m0 + 32 wave, first column of the tile)
+#pragma unroll
+        for (int j4 = 0; j4 < FPH / 4; ++j4)
+            *reinterpret_cast<f32x4*>(strip + l31 * STW + hf * FPH + 4 * j4) = f32x4{v[4 * j4], v[4 * j4 + 1], v[4 * j4 + 2], v[4 * j4 + 3]};
+        const int pc = lane % PPR, rs = lane / PPR;
+#pragma unroll
+        for (int k = 0; k < 32 / RPI; ++k) {
+            const int rr = rs + RPI * k;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(strip + rr * STW + 4 * pc);
+            if (wave * 32 + rr < mrem) *reinterpret_cast<f32x4*>(dst + (long long)rr * ld + 4 * pc) = t;
+        }
+    };
     const float* xrow = a.x + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     float* dxrow = a.dx + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     const float* dyrow = a.dy + grow * a.ldy + hf * 8;
@@ -447,23 +467,25 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
                     dxacc[j] += dsum;
                     if constexpr (RBF) duv[j] = usum;
                 }
-                if constexpr (RBF) {
-                    if (a.du && row_ok) {
-                        float* durow = a.du + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC;
-#pragma unroll
-                        for (int j = 0; j < FPH; ++j) durow[j] = duv[j];
+                if constexpr (STRIP) {
+                    if constexpr (RBF) {
+                        if (a.du) store_tile(duv, a.du + (m0 + wave * 32) * a.ldu + (long long)g * a.I + ci * IC, a.ldu);
                     }
-                }
-                if (p == NSH - 1 && row_ok) {
-                    if constexpr (FPH % 4 == 0) {
+                    if (p == NSH - 1) store_tile(dxacc, a.dx + (m0 + wave * 32) * a.ldx + (long long)gx * a.I + ci * IC, a.ldx);
+                } else {
+                    if constexpr (RBF) {
+                        if (a.du && row_ok) {
+                            float* durow = a.du + grow * a.ldu + (long long)g * a.I + hf * FPH + ci * IC;
+#pragma unroll
+                            for (int j = 0; j < FPH; ++j) durow[j] = duv[j];
+                        }
+                    }
+                    if (p == NSH - 1 && row_ok) {
 #pragma unroll
                         for (int j4 = 0; j4 < FPH / 4; ++j4) {
                             const f32x4 v = {dxacc[4 * j4], dxacc[4 * j4 + 1], dxacc[4 * j4 + 2], dxacc[4 * j4 + 3]};
                             *reinterpret_cast<f32x4*>(dxrow + ci * IC + 4 * j4) = v;
                         }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < FPH; ++j) dxrow[ci * IC + j] = dxacc[j];
                     }
                 }
                 if (!SHARED && p < NSH - 1) {
@@ -504,19 +526,23 @@ int launch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
     if constexpr (FAM != KV_SINE) {
         if (a.O == 64 && (nshare == 1 || nshare == 3) && !kv_config().bi_no_res) {      // the per-head layers: dY resident (see the kernel)
-            const size_t lds3 = (size_t)3 * 4 * 2 * 32 * KT * 16;      // a ring of three W step images
+            constexpr int IC_ = 2 * ((16 * KT) / GP);
+            const size_t lds3 = (size_t)3 * 4 * 2 * 32 * KT * 16 + sizeof(float) * 4 * 32 * (IC_ + 4);      // a ring of three W step images + four store strips
             if (nshare == 1) {
+                KV_ALLOW_LDS(160 * 1024, (kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 1, false>));
                 hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 1, false>), grid, dim3(256), lds3, st, a);
                 KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
                 return 0;
             }
             if (shared) {
                 if constexpr (kv_shared_basis<FAM>()) {
+                    KV_ALLOW_LDS(160 * 1024, (kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, true>));
                     hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, true>), grid, dim3(256), lds3, st, a);
                     KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
                     return 0;
                 }
             } else {
+                KV_ALLOW_LDS(160 * 1024, (kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, false>));
                 hipLaunchKernelGGL((kan_bwd_input_res_bf16_kernel<FAM, GP, KT, 3, false>), grid, dim3(256), lds3, st, a);
                 KV_LAUNCH_CHECK("kan_bwd_input_res_bf16_kernel");
                 return 0;

@@ -727,7 +727,7 @@ BwRegPlan plan_bwd_weight_reg(const kanvit_layer_desc* d) {
     // Small launches (the T / C geometries: 6400 rows, 2 heads): even at the shortest slab (64 tokens) the wave units cannot
     // fill the chip, and a wave's MFMA chain (tokens x GP x NOT) IS the kernel time.  One column tile per wave instead of
     // three: three times the waves, a third of the chain each; the basis is re-evaluated per wave (cheap against the chain).
-    if (fam == KANVIT_CHEBY && p.nt == 3 && (long long)p.nbg * p.nfb * p.nos * (d->M / 64) < 4LL * N_CU) {
+    if (fam == KANVIT_CHEBY && p.nt == 3 && (long long)p.nbg * p.nfb * p.nos * (d->M / 64) < 4LL * N_CU && !kv_config().bw_dma_force) {
         p.nt = 1;
         p.nos = p.tiles_per_bg;
     }
