@@ -348,14 +348,34 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     };
 
     // ---- prologue: ALL of this row's dY (NSH groups x 64 columns; this lane: its 8 of every 16), x of chunk 0, then W of steps 0 and 1 ----
+    // STRIP: the same bytes as whole row segments -- lane = (row rs + RPD k, 16-byte piece pc) of a [32 rows][TW columns] tile, RPD rows of TW * 4
+    // contiguous bytes per instruction -- turned into the operand layout (lane = row, 8 of every 16 columns) by a pass through the
+    // wave's LDS strip.  Straight into the operand layout a load instruction touches 32 rows with two 16-byte pieces each, a 128-byte
+    // line is fetched by four instructions of each of four waves, and the L1 does not hold them: 1.25 GB of L2 requests for the 390 MB
+    // this launch moves (TCC_REQ, round 4).
+    constexpr int TW = IC >= 32 ? 32 : 16, PPD = TW / 4, RPD = 64 / PPD, NTD = 64 / TW, STD = TW + 4;      // NTD tiles per group
     f32x4 raw[NSH][NKS][2];
+    f32x4 craw[STRIP ? NSH : 1][STRIP ? NTD : 1][STRIP ? 32 / RPD : 1];
+    if constexpr (STRIP) {
+        const int pc = lane % PPD, rs = lane / PPD;
 #pragma unroll
-    for (int p = 0; p < NSH; ++p) {
-        const float* src = dyrow + (long long)(p * a.xmod + gx) * a.O;
+        for (int p = 0; p < NSH; ++p)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            raw[p][ks][0] = *reinterpret_cast<const f32x4*>(src + 16 * ks);
-            raw[p][ks][1] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+            for (int h2 = 0; h2 < NTD; ++h2)
+#pragma unroll
+                for (int k = 0; k < 32 / RPD; ++k) {
+                    const int rr = wave * 32 + rs + RPD * k;
+                    craw[p][h2][k] = *reinterpret_cast<const f32x4*>(a.dy + (m0 + (rr < mrem ? rr : 0)) * a.ldy + (long long)(p * a.xmod + gx) * a.O + TW * h2 + 4 * pc);
+                }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NSH; ++p) {
+            const float* src = dyrow + (long long)(p * a.xmod + gx) * a.O;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                raw[p][ks][0] = *reinterpret_cast<const f32x4*>(src + 16 * ks);
+                raw[p][ks][1] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+            }
         }
     }
     load_x(0, xn);
@@ -366,6 +386,21 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     fill_w(0);
     if (T > 1) fill_w(1);
     bf16x8_t dyres[NSH][NKS];
+    if constexpr (STRIP) {
+        const int pc = lane % PPD, rs = lane / PPD;
+#pragma unroll
+        for (int p = 0; p < NSH; ++p)
+#pragma unroll
+            for (int h2 = 0; h2 < NTD; ++h2) {
+#pragma unroll
+                for (int k = 0; k < 32 / RPD; ++k) *reinterpret_cast<f32x4*>(strip + (rs + RPD * k) * STD + 4 * pc) = craw[p][h2][k];
+#pragma unroll
+                for (int ksl = 0; ksl < TW / 16; ++ksl) {
+                    raw[p][h2 * (TW / 16) + ksl][0] = *reinterpret_cast<const f32x4*>(strip + l31 * STD + 16 * ksl + 8 * hf);
+                    raw[p][h2 * (TW / 16) + ksl][1] = *reinterpret_cast<const f32x4*>(strip + l31 * STD + 16 * ksl + 8 * hf + 4);
+                }
+            }
+    }
 #pragma unroll
     for (int p = 0; p < NSH; ++p)
 #pragma unroll

@@ -442,7 +442,7 @@ int kanvit_layer_bwd_input(const kanvit_layer_desc* d, const float* x, const flo
     hipStream_t st = (hipStream_t)stream;
     if (a.wb2) {
         const BwdRegBf16Plan pr = plan_bwd_input_reg_bf16(d);
-        if (pr.ok && !(((uintptr_t)x | (uintptr_t)dx | (uintptr_t)(u ? u : x) | (uintptr_t)(du ? du : dx)) & 15)) {
+        if (pr.ok && !(((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dy | (uintptr_t)(u ? u : x) | (uintptr_t)(du ? du : dx)) & 15)) {
             return kv_bwd_input_reg_bf16(d->family, a, pr, st);
         }
         if (a.ln || d->O > 64 || d->family == KANVIT_SINE) a.wb2 = nullptr;     // no LayerNorm fusion / no wide layers in the LDS-tile bf16 kernel: the exact register kernel runs instead
