@@ -38,7 +38,10 @@ __global__ __launch_bounds__(256) void kan_bwd_weight_reg_kernel(const LayerArgs
     constexpr bool RBF = (FAM == KV_RBF);
     constexpr int TS = BF ? 8 : 1;            // tokens per lane per step
     constexpr int UB = BF ? 1 : 4;            // steps per prefetch block
-    constexpr int PD = BF ? 3 : 2;            // blocks in flight
+    // blocks in flight.  bf16 mode: three -- two for the G = 28 windows (256 accumulators: a third ring slot cost them 14 - 20 spilled registers
+    // inside the loop; with two, 1 - 2, and the patch-matrix passes of the bf16 Sine+Fourier config went 2.48 / 2.62 -> 2.42 / 2.51 ms).  The
+    // B-spline instantiation keeps three although it spills 32 registers with them: two measured 267 against 257 us on the ViT-B q|k|v launch.
+    constexpr int PD = BF ? (GP >= 28 ? 2 : 3) : 2;
     constexpr int NTOK = TS * UB;             // tokens per lane per block
     // The wave index is uniform by construction; telling the compiler (readfirstlane) keeps everything derived from it -- unit
     // and slab numbers, tile columns, the slab's base pointers -- in scalar registers instead of one vector register each.

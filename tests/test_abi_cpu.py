@@ -266,3 +266,25 @@ def test_variant_build_script_has_no_source_list_of_its_own():
     sh = open(os.path.join(ROOT, "tools", "build_variant.sh")).read()
     assert "build.SOURCES" in sh and "build.FLAGS" in sh
     assert not any(s[:-4] + " " in sh for s in build.SOURCES)          # no hard-coded names left
+
+
+def test_kernels_with_hand_counted_waits_use_no_scratch(lib):
+    """The LDS-DMA weight gradient waits for its fills with explicit `s_waitcnt vmcnt(N)` (hipcc does not track LDS-DMA against ds_read):
+    a scratch access inside its loop would count in vmcnt and let a wait pass before the fill has landed -- silent wrong data.  The code
+    objects' own metadata (tools/kernel_meta.py: no GPU, no ROCm tool) must show no scratch at all for it; the same file backs DESIGN.md's
+    zero-spill statements for the other kernels of round 4 (one SGPR spilled into a VGPR lane is not scratch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_meta", os.path.join(ROOT, "tools", "kernel_meta.py"))
+    km = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(km)
+    from kanvit import build
+    ks = {km.demangled_short(n): k for n, k in km.kernels(build.LIB).items()}
+    assert len(ks) > 300
+    dma = [n for n in ks if n.startswith("kan_bwd_weight_dma_kernel")]
+    assert len(dma) == 2                                     # fp32 and bf16 ChebyKAN
+    for n in dma:
+        assert ks[n][".private_segment_fixed_size"] == 0 and ks[n][".vgpr_spill_count"] == 0 and ks[n][".sgpr_spill_count"] == 0, n
+    round4 = [n for n in ks if n.startswith(("kan_bwd_input_res_bf16_kernel", "attn16_fwd_kernel", "attn16_bwd_kernel", "kan_fwd_ws_bf16_kernel"))]
+    assert len(round4) >= 20
+    for n in round4:
+        assert ks[n][".private_segment_fixed_size"] == 0 and ks[n][".vgpr_spill_count"] == 0, n
