@@ -97,6 +97,22 @@ def test_descriptor_layout_and_errors(lib):
     d.M, d.I, d.O, d.groups, d.x_group_mod, d.ldx, d.ldy = 25216, 64, 64, 36, 12, 768, 2304
     ws = lib.kanvit_layer_bwd_weight_workspace(ctypes.byref(d))
     assert ws % (36 * 320 * 64 * 4) == 0 and ws > 0
+    # round 4: the ViT-B q|k|v launch takes the LDS-DMA form (five work-group slabs, each the ordered sum of four row ranges:
+    # a quarter of the register form's 21 slab partials); KANVIT_BW_NO_DMA gives the register plan back
+    assert ws == 5 * 36 * 320 * 64 * 4
+    os.environ["KANVIT_BW_NO_DMA"] = "1"
+    try:
+        lib.kanvit_config_reload()
+        assert lib.kanvit_layer_bwd_weight_workspace(ctypes.byref(d)) == 21 * 36 * 320 * 64 * 4
+    finally:
+        del os.environ["KANVIT_BW_NO_DMA"]
+        lib.kanvit_config_reload()
+    d.groups, d.x_group_mod, d.I, d.O, d.ldx, d.ldy = 1, 1, 768, 768, 768, 768        # one fp32 layer: the register form (whose sums the patch-gather kernel reproduces)
+    ws1 = lib.kanvit_layer_bwd_weight_workspace(ctypes.byref(d))
+    d.flags = _lib.FLAG_BF16_MFMA                                                      # ... and under the bf16 flag (192 units cannot fill 256 CUs with whole work-groups)
+    assert lib.kanvit_layer_bwd_weight_workspace(ctypes.byref(d)) == ws1
+    d.flags = 0
+    d.M, d.I, d.O, d.groups, d.x_group_mod, d.ldx, d.ldy = 25216, 64, 64, 36, 12, 768, 2304
     assert lib.kanvit_layer_fwd_workspace(ctypes.byref(d)) == 0            # exact fp32 path needs no scratch
     d.flags = _lib.FLAG_BF16_MFMA
     assert lib.kanvit_layer_fwd_workspace(ctypes.byref(d)) >= 36 * 320 * 64 * 2   # bf16 repack of the weights
