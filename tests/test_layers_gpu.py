@@ -329,6 +329,7 @@ def test_chebykan_weight_gradient_lds_dma_form(rows, amp, monkeypatch):
 
     x = xfull[:, :256].contiguous()
     x_off = xfull[:, 1:]                           # rows start 4 bytes off the 16-byte grid (and ldx = 257)
+    monkeypatch.delenv("KANVIT_BW_NO_DMA", raising=False)      # (a run of the parity files with the round-4 forms switched off must not switch this one off)
     monkeypatch.setenv("KANVIT_BW_DMA_FORCE", "1")
     _lib.reload_config()
     try:
@@ -371,6 +372,8 @@ def test_bf16_input_gradient_resident_form_is_bitwise_the_streaming_form(fam, ro
         (y * w).sum().backward()
         return x.grad.clone()
 
+    monkeypatch.delenv("KANVIT_BI_NO_RES", raising=False)
+    _lib.reload_config()
     res = [dx(), dx()]
     monkeypatch.setenv("KANVIT_BI_NO_RES", "1")
     _lib.reload_config()
