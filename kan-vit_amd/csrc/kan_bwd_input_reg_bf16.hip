@@ -286,8 +286,17 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     static_assert(NV % 256 == 0, "whole DMA instructions (KT * 256 vectors per buffer)");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hf = lane >> 5;
     const int gx = blockIdx.x;
-    const long long m0 = (long long)blockIdx.y * BM;
     const int nci = a.I / IC;
+    // launch tail (kv_tail_first_tile, as kan_bwd_input_reg_kernel): grid rows >= tail_y0 are row tile tail_y0 + t / nci restricted to the ONE feature
+    // chunk t % nci -- dx columns are independent, nothing is summed twice; such a piece still loads its rows' whole dY
+    int by = (int)blockIdx.y, ci0 = 0, ci1 = nci;
+    if (by >= a.tail_y0) {
+        const int t = by - a.tail_y0, tl = t / nci;
+        ci0 = t - tl * nci;
+        ci1 = ci0 + 1;
+        by = a.tail_y0 + tl;
+    }
+    const long long m0 = (long long)by * BM;
     const int mrem = (m0 + BM <= a.M) ? BM : (int)(a.M - m0);
     const int row = wave * 32 + l31;
     const bool row_ok = row < mrem;
@@ -316,14 +325,14 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     const float* xrow = a.x + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     float* dxrow = a.dx + grow * a.ldx + (long long)gx * a.I + hf * FPH;
     const float* dyrow = a.dy + grow * a.ldy + hf * 8;
-    const int T = nci * NSH;
+    const int T = (ci1 - ci0) * NSH;
 
     // W of step t (feature chunk t / NSH, group t % NSH) -> ring slot t % 3, by LDS-DMA: the packed image is copied as it stands, 16 bytes
     // per lane and instruction, WQ instructions per thread; no register, no ds_write.  Issued two steps ahead (see the loop).
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto fill_w = [&](int t) __attribute__((always_inline)) {
-        const int ci = t / NSH, g = (t - ci * NSH) * a.xmod + gx;
+        const int cl = t / NSH, ci = ci0 + cl, g = (t - cl * NSH) * a.xmod + gx;
         const unsigned short* src = a.wb2 + (((long long)g * nci + ci) * NV) * 8 + (long long)lane * 8;      // this lane's 16 bytes of a 1 KiB piece
         unsigned short* dst = W_s + (size_t)(t % 3) * WSZ;
 #pragma unroll
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
             }
         }
     }
-    load_x(0, xn);
+    load_x(ci0, xn);
     float2 ln_st = {0.0f, 1.0f};                  // KANVIT_FLAG_FUSED_LN: (mean, rstd) of this lane's row and x slice
     if constexpr (RBF) {
         if (a.ln) ln_st = *reinterpret_cast<const float2*>(a.stats + (grow * a.xmod + gx) * 2);
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
     f32x16 acc[KT];
     float dxacc[FPH];
     float lnp[RBF ? 2 * FPH : 1];
-    for (int ci = 0; ci < nci; ++ci) {
+    for (int ci = ci0; ci < ci1; ++ci) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -424,12 +433,12 @@ __global__ __launch_bounds__(256, 2) void kan_bwd_input_res_bf16_kernel(const La
             dxacc[j] = 0.0f;
             xv[j] = xn[j];
         }
-        if (ci + 1 < nci) load_x(ci + 1, xn);
+        if (ci + 1 < ci1) load_x(ci + 1, xn);
         // groups that share the basis (one chain rule per chunk): the group loop is unrolled, dyres[p] a register name; groups that only
         // share x (a chain rule per group -- three copies of it unrolled spilled 46 - 98 registers): a rolled loop that selects its dY
 #pragma unroll UNR
         for (int p = 0; p < NSH; ++p) {
-            const int t = ci * NSH + p;
+            const int t = (ci - ci0) * NSH + p;
             const int g = p * a.xmod + gx;
             bf16x8_t dyb[NKS];
 #pragma unroll
@@ -561,6 +570,10 @@ int launch_bwd_input_reg_bf16(LayerArgs& a, const BwdRegBf16Plan& p, hipStream_t
     dim3 grid((unsigned)a.xmod, (unsigned)((a.M + BM - 1) / BM), 1);
     if constexpr (FAM != KV_SINE) {
         if (a.O == 64 && (nshare == 1 || nshare == 3) && !kv_config().bi_no_res) {      // the per-head layers: dY resident (see the kernel)
+            const long long tiles = (a.M + BM - 1) / BM;
+            if (p.nci > 1) a.tail_y0 = kv_tail_first_tile(tiles, a.xmod);
+            const long long t1 = a.tail_y0 < tiles ? a.tail_y0 : tiles;
+            grid.y = (unsigned)(t1 + (long long)p.nci * (tiles - t1));
             constexpr int IC_ = 2 * ((16 * KT) / GP);
             const size_t lds3 = (size_t)3 * 4 * 2 * 32 * KT * 16 + sizeof(float) * 4 * 32 * (IC_ + 4);      // a ring of three W step images + four store strips
             if (nshare == 1) {
